@@ -1,0 +1,45 @@
+# Build of the MI355X curve-number generator.
+#   make            everything that builds without a GPU (hipcc cross-compiles gfx950)
+#   make gpu        libgcn10_gpu.so   (HIP kernels + C ABI, include/gcn10_gpu.h)
+#   make host       libgcn10_host.so  (C99 host library, include/gcn10_host.h)
+#   make cli        bin/gcn10         (drop-in for the reference's src/ program)
+#   make oracle     oracle/libcn_oracle.so (test infrastructure only)
+HIPCC   ?= /opt/rocm/bin/hipcc
+CC      ?= gcc
+ARCH    ?= gfx950
+PKG     := gcn10_amd
+CSRC    := $(PKG)/csrc
+HOSTSRC := $(wildcard $(CSRC)/host/*.c)
+HOSTLIBSRC := $(filter-out $(CSRC)/host/main.c,$(HOSTSRC))
+
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Wall
+# -ffp-contract=off: the fp64 index arithmetic must match the reference's
+# non-FMA build bit for bit (src/CMakeLists.txt:68 has no -march).
+CFLAGS  := -std=c99 -D_GNU_SOURCE -O2 -g -Wall -Wextra -fPIC -ffp-contract=off -Iinclude -pthread
+
+all: gpu host cli oracle
+
+gpu: $(PKG)/libgcn10_gpu.so
+host: $(PKG)/libgcn10_host.so
+oracle:
+	$(MAKE) -C oracle
+
+$(PKG)/libgcn10_gpu.so: $(CSRC)/gcn10_gpu.hip include/gcn10_gpu.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $<
+
+$(PKG)/libgcn10_host.so: $(HOSTLIBSRC) include/gcn10_host.h include/gcn10_gpu.h
+	$(CC) $(CFLAGS) -shared -o $@ $(HOSTLIBSRC) -lm -lz -ldl
+
+ifneq ($(wildcard $(CSRC)/host/main.c),)
+cli: bin/gcn10
+bin/gcn10: $(CSRC)/host/main.c $(PKG)/libgcn10_host.so
+	mkdir -p bin
+	$(CC) $(CFLAGS) -o $@ $(CSRC)/host/main.c -L$(PKG) -lgcn10_host -Wl,-rpath,'$$ORIGIN/../$(PKG)' -lm -lz -ldl
+else
+cli:
+endif
+
+clean:
+	rm -f $(PKG)/*.so bin/gcn10
+	$(MAKE) -C oracle clean
+.PHONY: all gpu host cli oracle clean

@@ -1,0 +1,1156 @@
+// gcn10_gpu.hip -- MI355X (gfx950 / CDNA4) curve-number engine behind the C ABI
+// of include/gcn10_gpu.h.  Written for gfx950 only: 64-lane waves, 16-byte
+// per-lane global accesses (1 KiB per wave instruction), lookup tables in LDS.
+//
+// Reference behaviour restated here (citations are /root/reference paths):
+//   src/cn.c:218-232   HSG nearest-neighbour upsample  -> x-expand + row pick
+//   src/cn.c:88-111    modify_hysogs_data              -> soil-code byte (sD | sU<<4)
+//   src/cn.c:114-131   calculate_cn                    -> LDS table gather
+//   src/cn.c:236-290   18 (cond, hc, arc) passes       -> one pass, 18 store streams
+//
+// Data layout in HBM (all rasters uint8, row-major, exactly the reference's
+// malloc'd buffers, src/raster.c:169-178):
+//   esa      [rows*W]            landcover strip, read once, 16 B / lane
+//   out[r]   [rows*W]  r < 18    CN rasters, written once, 16 B / lane, nontemporal
+//   hx       [hsy][hx_stride]    soil window expanded along x only, one byte per
+//                                fine column holding both remapped soil groups;
+//                                52 MB for a 36000-wide block, re-read ~25x per
+//                                row from L2 / Infinity Cache, once from HBM
+//   lut16    [6][256] x 16 B     row (s, lc): bytes 0..8 = CN of tables 0..8,
+//                                plane s=5 is all 255 (soil group not in 0..4)
+//   lut1[k]  [6][256] x 1 B      the same for a single table k
+//
+// The dominant kernel (cn_strip_*) is HBM-bound: 1 + n_out bytes per pixel of
+// DRAM traffic against ~20 VALU ops and 2 ds_read_b128 per pixel.
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "gcn10_gpu.h"
+
+namespace {
+
+// ------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                          \
+    do {                                                                       \
+        hipError_t e_ = (expr);                                                \
+        if (e_ != hipSuccess)                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? GCN10_E_NOMEM : GCN10_E_HIP, \
+                        "%s: %s", #expr, hipGetErrorString(e_));               \
+    } while (0)
+
+// ------------------------------------------------------------------------
+// constants shared by host and device
+// ------------------------------------------------------------------------
+constexpr int kThreads = 256;           // 4 waves per workgroup
+constexpr int kPxPerLane = 16;          // one dwordx4 per lane per stream
+constexpr int kChunk = kThreads * kPxPerLane;   // 4096 px per workgroup step
+constexpr int kPlanes = 6;              // soil groups 0..4 + "invalid" plane
+constexpr int kInvalidPlane = 5;
+// LDS plane stride for the 16-byte-row table: 256 rows + one row of padding so
+// that equal landcover classes in different planes fall in different banks.
+constexpr int kPlane16 = 256 * 16 + 16;
+constexpr int kLut16Bytes = kPlanes * kPlane16;
+// LDS plane stride for the single-table byte LUT (+4 B pad: next bank).
+constexpr int kPlane1 = 256 + 4;
+constexpr int kLut1Bytes = kPlanes * kPlane1;
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct StripParams {
+    const uint8_t *esa;
+    const uint8_t *hx;      // x-expanded soil codes
+    const int32_t *cj;      // coarse row of every strip row
+    const uint8_t *lut;     // device image of the LDS table (lut16 or lut1[k])
+    uint8_t *out[GCN10_N_RASTERS];
+    uint32_t W;
+    uint32_t rows;
+    uint32_t npix;          // W*rows (< 2^31, as the reference's int npix, src/cn.c:208)
+    uint32_t hx_stride;
+    uint32_t hx_rows;       // rows in hx; cj is clamped to it defensively
+    uint32_t nchunks;
+    uint32_t table_mask;
+    uint32_t single_k;      // table index for the single-table variant
+};
+
+// soil code byte: low nibble = plane for "drained", high nibble = "undrained".
+// src/cn.c:92-110 followed by the `soil_group < 5` test of src/cn.c:123-124.
+__host__ __device__ inline uint8_t soil_code(uint8_t h)
+{
+    uint8_t d, u;
+    if (h >= 11 && h <= 14) {
+        d = 4;                  // drained: every dual class acts as D
+        u = (uint8_t)(h - 10);  // undrained: 11..14 -> 1..4
+    }
+    else {
+        d = u = (h < 5) ? h : (uint8_t)kInvalidPlane;
+    }
+    return (uint8_t)(d | (u << 4));
+}
+
+// ------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------
+
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte pool {hi:lo}
+// (selector 0..3 -> lo bytes 0..3, 4..7 -> hi bytes 0..3).
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+    return __builtin_amdgcn_perm(hi, lo, sel);
+}
+
+// 4x4 byte transpose: in a,b,c,d = one dword (4 table values) of pixels 0..3;
+// out o[k] = {a.byte k, b.byte k, c.byte k, d.byte k} (pixel 0 in the low byte).
+__device__ __forceinline__ void transpose4x4(uint32_t a, uint32_t b, uint32_t c,
+                                             uint32_t d, uint32_t &o0, uint32_t &o1,
+                                             uint32_t &o2, uint32_t &o3)
+{
+    uint32_t t0 = perm(b, a, 0x05010400u);  // a0 b0 a1 b1
+    uint32_t t1 = perm(b, a, 0x07030602u);  // a2 b2 a3 b3
+    uint32_t t2 = perm(d, c, 0x05010400u);  // c0 d0 c1 d1
+    uint32_t t3 = perm(d, c, 0x07030602u);  // c2 d2 c3 d3
+    o0 = perm(t2, t0, 0x05040100u);         // a0 b0 c0 d0
+    o1 = perm(t2, t0, 0x07060302u);         // a1 b1 c1 d1
+    o2 = perm(t3, t1, 0x05040100u);         // a2 b2 c2 d2
+    o3 = perm(t3, t1, 0x07060302u);         // a3 b3 c3 d3
+}
+
+__device__ __forceinline__ uint32_t gather_byte0(uint32_t a, uint32_t b, uint32_t c,
+                                                 uint32_t d)
+{
+    uint32_t t0 = perm(b, a, 0x0c0c0400u);  // a0 b0 0 0
+    uint32_t t1 = perm(d, c, 0x04000c0cu);  // 0 0 c0 d0
+    return t0 | t1;
+}
+
+__device__ __forceinline__ u32x4 load16_aligned(const uint8_t *p)
+{
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+}
+
+__device__ __forceinline__ u32x4 load16_any(const uint8_t *p)
+{
+    // gfx950 runs with unaligned global access enabled; tell the compiler the
+    // pointer is only byte aligned and let it pick the widest legal load.
+    typedef u32x4 u32x4_u __attribute__((aligned(1)));
+    return *reinterpret_cast<const u32x4_u *>(p);
+}
+
+__device__ __forceinline__ void store16(uint8_t *p, u32x4 v)
+{
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
+}
+
+// Coarse soil row of strip row y.  cj comes from the caller (host-built, already
+// clamped as src/cn.c:229 does); the extra min() only keeps a bad map from
+// reading outside the workspace.
+__device__ __forceinline__ uint32_t soil_row(const StripParams &p, uint32_t y)
+{
+    const uint32_t r = (uint32_t)p.cj[y];
+    return r < p.hx_rows ? r : p.hx_rows - 1u;
+}
+
+// Split a flat strip index into (row, column).  `wave_base` is uniform over
+// the wave, so its division runs once per wave on uniform values; a lane only
+// divides again when its own 16 pixels start in a later row.
+__device__ __forceinline__ void flat_to_xy(uint32_t wave_base, uint32_t lane_off,
+                                           uint32_t W, uint32_t &y, uint32_t &x)
+{
+    uint32_t wb = __builtin_amdgcn_readfirstlane(wave_base);
+    uint32_t yb = wb / W;
+    uint32_t xb = wb - yb * W;
+    uint32_t xx = xb + lane_off;
+    uint32_t yy = yb;
+    if (xx >= W) {
+        uint32_t q = xx / W;
+        yy += q;
+        xx -= q * W;
+    }
+    y = yy;
+    x = xx;
+}
+
+// Workgroup -> chunk mapping.  Workgroups are dealt round-robin over the 8
+// XCDs (b and b+8 share one L2), so give each XCD a contiguous slab of the
+// strip: the x-expanded soil rows a slab re-reads then stay in that XCD's L2.
+__device__ __forceinline__ uint32_t first_chunk(uint32_t nchunks, uint32_t &step,
+                                                uint32_t &end)
+{
+    uint32_t nb = gridDim.x;
+    uint32_t b = blockIdx.x;
+    if (nb % 8u == 0u && nchunks >= nb) {
+        uint32_t xcd = b & 7u;
+        uint32_t per = (nchunks + 7u) / 8u;
+        uint32_t lo = xcd * per;
+        uint32_t hi = lo + per < nchunks ? lo + per : nchunks;
+        step = nb / 8u;
+        end = hi;
+        return lo + (b >> 3);
+    }
+    step = nb;
+    end = nchunks;
+    return b;
+}
+
+// ------------------------------------------------------------------------
+// cn_strip, all-tables variant: one 16-byte LDS row per (soil plane, class)
+// holds the CN of all nine tables, so a pixel costs one ds_read_b128 per
+// drainage condition whatever the number of rasters written.
+// ------------------------------------------------------------------------
+template <int COND_MASK, bool ALL_TABLES>
+__global__ __launch_bounds__(kThreads) void cn_strip_lut16(const StripParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lut[kLut16Bytes];
+
+    {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(p.lut);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(lut);
+        for (int i = threadIdx.x; i < kLut16Bytes / 16; i += kThreads)
+            dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const uint32_t lane_off = (threadIdx.x & 63u) * kPxPerLane;
+    const uint32_t wave_off = (threadIdx.x >> 6) * 64u * kPxPerLane;
+    const uint32_t tmask = ALL_TABLES ? 0x1ffu : p.table_mask;
+
+    uint32_t step, end;
+    for (uint32_t chunk = first_chunk(p.nchunks, step, end); chunk < end; chunk += step) {
+        const uint32_t wave_base = chunk * (uint32_t)kChunk + wave_off;
+        const uint32_t i0 = wave_base + lane_off;
+        if (i0 >= p.npix)
+            continue;
+        uint32_t y, x0;
+        flat_to_xy(wave_base, lane_off, p.W, y, x0);
+
+        if (i0 + kPxPerLane <= p.npix && x0 + kPxPerLane <= p.W) {
+            // ---- fast path: 16 pixels of one row ----
+            const u32x4 e16 = load16_aligned(p.esa + i0);
+            const uint32_t r = soil_row(p, y);
+            const u32x4 c16 = load16_any(p.hx + (size_t)r * p.hx_stride + x0);
+
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                if (!(COND_MASK & (1 << c)))
+                    continue;
+                uint32_t acc[9][4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t e = e16[j];
+                    const uint32_t cd = c16[j];
+                    u32x4 row[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t lc16 = q == 0 ? (e << 4) & 0xff0u
+                                                     : (e >> (8 * q - 4)) & 0xff0u;
+                        const uint32_t s = (cd >> (8 * q + 4 * c)) & 0xfu;
+                        const uint32_t addr = s * (uint32_t)kPlane16 + lc16;
+                        row[q] = *reinterpret_cast<const u32x4 *>(lut + addr);
+                    }
+                    transpose4x4(row[0][0], row[1][0], row[2][0], row[3][0],
+                                 acc[0][j], acc[1][j], acc[2][j], acc[3][j]);
+                    transpose4x4(row[0][1], row[1][1], row[2][1], row[3][1],
+                                 acc[4][j], acc[5][j], acc[6][j], acc[7][j]);
+                    acc[8][j] = gather_byte0(row[0][2], row[1][2], row[2][2], row[3][2]);
+                }
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    if (tmask & (1u << k)) {
+                        u32x4 v = {acc[k][0], acc[k][1], acc[k][2], acc[k][3]};
+                        store16(p.out[c * 9 + k] + i0, v);
+                    }
+                }
+            }
+        }
+        else {
+            // ---- slow path: strip tail or a lane that straddles rows ----
+            uint32_t yy = y, xx = x0;
+            for (uint32_t q = 0; q < (uint32_t)kPxPerLane; q++) {
+                const uint32_t i = i0 + q;
+                if (i >= p.npix)
+                    break;
+                const uint32_t lc = p.esa[i];
+                const uint32_t cd = p.hx[(size_t)soil_row(p, yy) * p.hx_stride + xx];
+                for (int c = 0; c < 2; c++) {
+                    if (!(COND_MASK & (1 << c)))
+                        continue;
+                    const uint32_t s = (cd >> (4 * c)) & 0xfu;
+                    const uint8_t *row = lut + s * (uint32_t)kPlane16 + lc * 16u;
+                    for (int k = 0; k < 9; k++)
+                        if (tmask & (1u << k))
+                            p.out[c * 9 + k][i] = row[k];
+                }
+                if (++xx == p.W) {
+                    xx = 0;
+                    yy++;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
+// cn_strip, single-table variant (BASELINE config 2: one lookup, 2-3 B/px of
+// HBM traffic, so the pixel rate is ~8x the all-tables kernel's and the LDS
+// work per pixel must be one byte read, not a 16-byte row).
+// ------------------------------------------------------------------------
+template <int COND_MASK>
+__global__ __launch_bounds__(kThreads) void cn_strip_lut1(const StripParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lut[kLut1Bytes];
+
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(p.lut);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(lut);
+        for (int i = threadIdx.x; i < kLut1Bytes / 4; i += kThreads)
+            dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const uint32_t lane_off = (threadIdx.x & 63u) * kPxPerLane;
+    const uint32_t wave_off = (threadIdx.x >> 6) * 64u * kPxPerLane;
+    const uint32_t k = p.single_k;
+
+    uint32_t step, end;
+    for (uint32_t chunk = first_chunk(p.nchunks, step, end); chunk < end; chunk += step) {
+        const uint32_t wave_base = chunk * (uint32_t)kChunk + wave_off;
+        const uint32_t i0 = wave_base + lane_off;
+        if (i0 >= p.npix)
+            continue;
+        uint32_t y, x0;
+        flat_to_xy(wave_base, lane_off, p.W, y, x0);
+
+        if (i0 + kPxPerLane <= p.npix && x0 + kPxPerLane <= p.W) {
+            const u32x4 e16 = load16_aligned(p.esa + i0);
+            const uint32_t r = soil_row(p, y);
+            const u32x4 c16 = load16_any(p.hx + (size_t)r * p.hx_stride + x0);
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                if (!(COND_MASK & (1 << c)))
+                    continue;
+                u32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t e = e16[j];
+                    const uint32_t cd = c16[j];
+                    uint32_t w = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t lc = (e >> (8 * q)) & 0xffu;
+                        const uint32_t s = (cd >> (8 * q + 4 * c)) & 0xfu;
+                        const uint32_t b = lut[s * (uint32_t)kPlane1 + lc];
+                        w |= b << (8 * q);
+                    }
+                    v[j] = w;
+                }
+                store16(p.out[c * 9 + k] + i0, v);
+            }
+        }
+        else {
+            uint32_t yy = y, xx = x0;
+            for (uint32_t q = 0; q < (uint32_t)kPxPerLane; q++) {
+                const uint32_t i = i0 + q;
+                if (i >= p.npix)
+                    break;
+                const uint32_t lc = p.esa[i];
+                const uint32_t cd = p.hx[(size_t)soil_row(p, yy) * p.hx_stride + xx];
+                for (int c = 0; c < 2; c++) {
+                    if (!(COND_MASK & (1 << c)))
+                        continue;
+                    const uint32_t s = (cd >> (4 * c)) & 0xfu;
+                    p.out[c * 9 + k][i] = lut[s * (uint32_t)kPlane1 + lc];
+                }
+                if (++xx == p.W) {
+                    xx = 0;
+                    yy++;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
+// byte-wise strip kernel: any alignment, any shape.  Used when a raster
+// pointer is not 16-byte aligned (never the case for the host pipeline).
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void cn_strip_bytes(const StripParams p,
+                                                           uint32_t cond_mask)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lut[kLut16Bytes];
+    for (int i = threadIdx.x; i < kLut16Bytes; i += kThreads)
+        lut[i] = p.lut[i];
+    __syncthreads();
+
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < p.npix; i += stride) {
+        const uint32_t y = i / p.W;
+        const uint32_t x = i - y * p.W;
+        const uint32_t lc = p.esa[i];
+        const uint32_t cd = p.hx[(size_t)soil_row(p, y) * p.hx_stride + x];
+        for (int c = 0; c < 2; c++) {
+            if (!(cond_mask & (1u << c)))
+                continue;
+            const uint32_t s = (cd >> (4 * c)) & 0xfu;
+            const uint8_t *row = lut + s * (uint32_t)kPlane16 + lc * 16u;
+            for (int k = 0; k < 9; k++)
+                if (p.table_mask & (1u << k))
+                    p.out[c * 9 + k][i] = row[k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
+// x-expansion of the coarse soil window (the x half of src/cn.c:218-232).
+// CODE = true : write soil_code(h) for the fused path (hx workspace)
+// CODE = false: write h itself (gcn10_gpu_resample, row picked by cj too)
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void expand_x_codes(const uint8_t *coarse,
+                                                           uint32_t hsx, uint32_t hsy,
+                                                           const int32_t *ci, uint32_t W,
+                                                           uint8_t *hx, uint32_t hx_stride)
+{
+    const uint32_t x = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
+    const uint32_t r = blockIdx.y;
+    if (x >= hx_stride)
+        return;
+    const uint8_t *row = coarse + (size_t)r * hsx;
+    uint32_t w = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        // columns past W are padding: give them the "invalid" code
+        uint8_t code = (uint8_t)(kInvalidPlane | (kInvalidPlane << 4));
+        if (x + q < W) {
+            const uint32_t cx = (uint32_t)ci[x + q];
+            code = soil_code(row[cx < hsx ? cx : hsx - 1u]);
+        }
+        w |= (uint32_t)code << (8 * q);
+    }
+    *reinterpret_cast<uint32_t *>(hx + (size_t)r * hx_stride + x) = w;
+}
+
+__global__ __launch_bounds__(kThreads) void resample_rows(const uint8_t *coarse,
+                                                          uint32_t hsx,
+                                                          const int32_t *ci,
+                                                          const int32_t *cj, uint32_t W,
+                                                          uint32_t rows, uint8_t *out)
+{
+    const size_t npix = (size_t)W * rows;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
+        const uint32_t y = (uint32_t)(i / W);
+        const uint32_t x = (uint32_t)(i - (size_t)y * W);
+        out[i] = coarse[(size_t)(uint32_t)cj[y] * hsx + (uint32_t)ci[x]];   // src/cn.c:230
+    }
+}
+
+// ------------------------------------------------------------------------
+// modify_hysogs_data (src/cn.c:88-111), in place
+// ------------------------------------------------------------------------
+__device__ __forceinline__ uint8_t remap_soil(uint8_t h, bool drained)
+{
+    if (h >= 11 && h <= 14)
+        return drained ? (uint8_t)4 : (uint8_t)(h - 10);
+    return h;
+}
+
+__global__ __launch_bounds__(kThreads) void modify_hysogs_kernel(uint8_t *h, size_t npix,
+                                                                 int drained,
+                                                                 size_t head, size_t nvec)
+{
+    // [0, head) bytes, then nvec aligned 16-byte groups, then the tail bytes
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    u32x4 *body = reinterpret_cast<u32x4 *>(h + head);
+    for (size_t v = tid; v < nvec; v += stride) {
+        u32x4 in = body[v];
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                w |= (uint32_t)remap_soil((uint8_t)(in[j] >> (8 * q)), drained != 0) << (8 * q);
+            o[j] = w;
+        }
+        body[v] = o;
+    }
+    const size_t tail0 = head + nvec * 16;
+    const size_t nscalar = head + (npix - tail0);
+    for (size_t s = tid; s < nscalar; s += stride) {
+        const size_t i = s < head ? s : tail0 + (s - head);
+        h[i] = remap_soil(h[i], drained != 0);
+    }
+}
+
+// ------------------------------------------------------------------------
+// calculate_cn (src/cn.c:114-131) on a full-resolution soil raster
+// ------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void calculate_cn_kernel(const uint8_t *esa,
+                                                                const uint8_t *hsg,
+                                                                size_t npix,
+                                                                const uint8_t *lut_img,
+                                                                uint8_t *out)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lut[kLut1Bytes];
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(lut_img);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(lut);
+        for (int i = threadIdx.x; i < kLut1Bytes / 4; i += kThreads)
+            dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nvec = VEC ? npix / 16 : 0;
+    if (VEC) {
+        for (size_t v = tid; v < nvec; v += stride) {
+            const u32x4 e16 = load16_aligned(esa + v * 16);
+            const u32x4 h16 = load16_aligned(hsg + v * 16);
+            u32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t lc = (e16[j] >> (8 * q)) & 0xffu;
+                    uint32_t s = (h16[j] >> (8 * q)) & 0xffu;
+                    s = s < 5u ? s : (uint32_t)kInvalidPlane;   // src/cn.c:123-124
+                    w |= (uint32_t)lut[s * (uint32_t)kPlane1 + lc] << (8 * q);
+                }
+                o[j] = w;
+            }
+            store16(out + v * 16, o);
+        }
+    }
+    for (size_t i = nvec * 16 + tid; i < npix; i += stride) {
+        const uint32_t lc = esa[i];
+        uint32_t s = hsg[i];
+        s = s < 5u ? s : (uint32_t)kInvalidPlane;
+        out[i] = lut[s * (uint32_t)kPlane1 + lc];
+    }
+}
+
+inline bool aligned16(const void *p)
+{
+    return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
+inline int popcount(unsigned v)
+{
+    return __builtin_popcount(v);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------
+struct gcn10_gpu_ctx {
+    int device = -1;
+    int n_cus = 0;
+    hipStream_t main_stream = nullptr;
+    uint8_t *d_lut16 = nullptr;     // kLut16Bytes
+    uint8_t *d_lut1 = nullptr;      // 9 * kLut1Bytes
+    int n_tables = 0;
+    uint8_t *d_hx = nullptr;
+    size_t hx_capacity = 0;
+    uint32_t hx_stride = 0;
+    uint32_t hx_W = 0;
+    uint32_t hx_rows = 0;
+    const char *last_kernel = "";
+    int grid_blocks_per_cu = 8;
+};
+
+namespace {
+
+int use_device(gcn10_gpu_ctx *ctx)
+{
+    if (!ctx)
+        return fail(GCN10_E_INVAL, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return GCN10_OK;
+}
+
+inline hipStream_t as_stream(gcn10_gpu_ctx *ctx, gcn10_stream_t s)
+{
+    return s ? reinterpret_cast<hipStream_t>(s) : ctx->main_stream;
+}
+
+// Memory-bound streaming grid: a few workgroups per CU, each looping over
+// chunks; a multiple of 8 so every XCD gets the same number.
+uint32_t stream_grid(const gcn10_gpu_ctx *ctx, uint64_t nchunks)
+{
+    uint64_t cap = (uint64_t)ctx->n_cus * ctx->grid_blocks_per_cu;
+    cap -= cap % 8u;
+    if (cap < 8)
+        cap = 8;
+    uint64_t g = nchunks < cap ? nchunks : cap;
+    return (uint32_t)(g ? g : 1);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------
+extern "C" {
+
+int gcn10_gpu_abi_version(void)
+{
+    return GCN10_GPU_ABI_VERSION;
+}
+
+const char *gcn10_gpu_last_error(void)
+{
+    return g_err;
+}
+
+int gcn10_gpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int gcn10_gpu_init(int device, gcn10_gpu_ctx **out)
+{
+    if (!out)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_init: null out pointer");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(GCN10_E_NODEVICE, "no HIP device visible (%s); this engine has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= n)
+        return fail(GCN10_E_INVAL, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(GCN10_E_NODEVICE, "device %d is %s; this library carries gfx950 code only",
+                    device, prop.gcnArchName);
+
+    gcn10_gpu_ctx *ctx = new (std::nothrow) gcn10_gpu_ctx();
+    if (!ctx)
+        return fail(GCN10_E_NOMEM, "context allocation failed");
+    ctx->device = device;
+    ctx->n_cus = prop.multiProcessorCount;
+    hipError_t e2 = hipStreamCreateWithFlags(&ctx->main_stream, hipStreamNonBlocking);
+    if (e2 == hipSuccess)
+        e2 = hipMalloc(reinterpret_cast<void **>(&ctx->d_lut16), kLut16Bytes);
+    if (e2 == hipSuccess)
+        e2 = hipMalloc(reinterpret_cast<void **>(&ctx->d_lut1), GCN10_N_TABLES * kLut1Bytes);
+    if (e2 != hipSuccess) {
+        int rc = fail(GCN10_E_HIP, "context setup: %s", hipGetErrorString(e2));
+        gcn10_gpu_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return GCN10_OK;
+}
+
+void gcn10_gpu_destroy(gcn10_gpu_ctx *ctx)
+{
+    if (!ctx)
+        return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->main_stream) {
+        (void)hipStreamSynchronize(ctx->main_stream);
+        (void)hipStreamDestroy(ctx->main_stream);
+    }
+    if (ctx->d_lut16)
+        (void)hipFree(ctx->d_lut16);
+    if (ctx->d_lut1)
+        (void)hipFree(ctx->d_lut1);
+    if (ctx->d_hx)
+        (void)hipFree(ctx->d_hx);
+    delete ctx;
+}
+
+int gcn10_gpu_device_info(gcn10_gpu_ctx *ctx, char *name, size_t cap, size_t *hbm_bytes)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    if (name && cap)
+        snprintf(name, cap, "%s (%s)", prop.name, prop.gcnArchName);
+    if (hbm_bytes)
+        *hbm_bytes = prop.totalGlobalMem;
+    return prop.multiProcessorCount;
+}
+
+// ---- memory / streams / events ------------------------------------------
+
+int gcn10_gpu_malloc(gcn10_gpu_ctx *ctx, size_t bytes, void **dptr)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (!dptr)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_malloc: null out pointer");
+    *dptr = nullptr;
+    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 1));
+    return GCN10_OK;
+}
+
+int gcn10_gpu_free(gcn10_gpu_ctx *ctx, void *dptr)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (dptr)
+        HIP_TRY(hipFree(dptr));
+    return GCN10_OK;
+}
+
+int gcn10_gpu_host_alloc(gcn10_gpu_ctx *ctx, size_t bytes, void **hptr)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (!hptr)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_host_alloc: null out pointer");
+    *hptr = nullptr;
+    HIP_TRY(hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return GCN10_OK;
+}
+
+int gcn10_gpu_host_free(gcn10_gpu_ctx *ctx, void *hptr)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (hptr)
+        HIP_TRY(hipHostFree(hptr));
+    return GCN10_OK;
+}
+
+int gcn10_gpu_memcpy_h2d(gcn10_gpu_ctx *ctx, void *dst, const void *src, size_t bytes,
+                         gcn10_stream_t stream)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (bytes && (!dst || !src))
+        return fail(GCN10_E_INVAL, "gcn10_gpu_memcpy_h2d: null pointer");
+    if (bytes)
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(ctx, stream)));
+    return GCN10_OK;
+}
+
+int gcn10_gpu_memcpy_d2h(gcn10_gpu_ctx *ctx, void *dst, const void *src, size_t bytes,
+                         gcn10_stream_t stream)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (bytes && (!dst || !src))
+        return fail(GCN10_E_INVAL, "gcn10_gpu_memcpy_d2h: null pointer");
+    if (bytes)
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(ctx, stream)));
+    return GCN10_OK;
+}
+
+int gcn10_gpu_memset(gcn10_gpu_ctx *ctx, void *dptr, int value, size_t bytes,
+                     gcn10_stream_t stream)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (bytes && !dptr)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_memset: null pointer");
+    if (bytes)
+        HIP_TRY(hipMemsetAsync(dptr, value, bytes, as_stream(ctx, stream)));
+    return GCN10_OK;
+}
+
+int gcn10_gpu_stream_create(gcn10_gpu_ctx *ctx, gcn10_stream_t *stream)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (!stream)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_stream_create: null out pointer");
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return GCN10_OK;
+}
+
+int gcn10_gpu_stream_destroy(gcn10_gpu_ctx *ctx, gcn10_stream_t stream)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (stream)
+        HIP_TRY(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)));
+    return GCN10_OK;
+}
+
+int gcn10_gpu_stream_sync(gcn10_gpu_ctx *ctx, gcn10_stream_t stream)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(as_stream(ctx, stream)));
+    return GCN10_OK;
+}
+
+int gcn10_gpu_device_sync(gcn10_gpu_ctx *ctx)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return GCN10_OK;
+}
+
+int gcn10_gpu_event_create(gcn10_gpu_ctx *ctx, gcn10_event_t *ev)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (!ev)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_event_create: null out pointer");
+    hipEvent_t e = nullptr;
+    HIP_TRY(hipEventCreate(&e));
+    *ev = e;
+    return GCN10_OK;
+}
+
+int gcn10_gpu_event_destroy(gcn10_gpu_ctx *ctx, gcn10_event_t ev)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (ev)
+        HIP_TRY(hipEventDestroy(reinterpret_cast<hipEvent_t>(ev)));
+    return GCN10_OK;
+}
+
+int gcn10_gpu_event_record(gcn10_gpu_ctx *ctx, gcn10_event_t ev, gcn10_stream_t stream)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (!ev)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_event_record: null event");
+    HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev), as_stream(ctx, stream)));
+    return GCN10_OK;
+}
+
+int gcn10_gpu_event_sync(gcn10_gpu_ctx *ctx, gcn10_event_t ev)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (!ev)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_event_sync: null event");
+    HIP_TRY(hipEventSynchronize(reinterpret_cast<hipEvent_t>(ev)));
+    return GCN10_OK;
+}
+
+int gcn10_gpu_stream_wait_event(gcn10_gpu_ctx *ctx, gcn10_stream_t stream, gcn10_event_t ev)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (!ev)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_stream_wait_event: null event");
+    HIP_TRY(hipStreamWaitEvent(as_stream(ctx, stream), reinterpret_cast<hipEvent_t>(ev), 0));
+    return GCN10_OK;
+}
+
+int gcn10_gpu_event_elapsed_ms(gcn10_gpu_ctx *ctx, gcn10_event_t start, gcn10_event_t stop,
+                               float *ms)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (!start || !stop || !ms)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_event_elapsed_ms: null argument");
+    HIP_TRY(hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start),
+                                reinterpret_cast<hipEvent_t>(stop)));
+    return GCN10_OK;
+}
+
+// ---- tables ---------------------------------------------------------------
+
+int gcn10_gpu_set_tables(gcn10_gpu_ctx *ctx, const int *tables, int n_tables)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (!tables || n_tables < 1 || n_tables > GCN10_N_TABLES)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_set_tables: need 1..9 tables, got %d", n_tables);
+
+    static thread_local uint8_t img16[kLut16Bytes];
+    static thread_local uint8_t img1[GCN10_N_TABLES * kLut1Bytes];
+    memset(img16, GCN10_NODATA, sizeof img16);
+    memset(img1, GCN10_NODATA, sizeof img1);
+    for (int k = 0; k < n_tables; k++) {
+        for (int lc = 0; lc < 256; lc++) {
+            for (int s = 0; s < 5; s++) {
+                const int v = tables[(k * 256 + lc) * 5 + s];
+                // src/cn.c:125-128: only values < 255 are stored, through a
+                // truncating (uint8_t) cast; everything else leaves the 255
+                // the raster was memset to (src/cn.c:289).
+                const uint8_t b = v < GCN10_NODATA ? (uint8_t)v : (uint8_t)GCN10_NODATA;
+                img16[s * kPlane16 + lc * 16 + k] = b;
+                img1[k * kLut1Bytes + s * kPlane1 + lc] = b;
+            }
+        }
+    }
+    // synchronous copies: set_tables is a once-per-run call and the images are
+    // reused by every later launch on any stream
+    HIP_TRY(hipMemcpy(ctx->d_lut16, img16, sizeof img16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_lut1, img1, sizeof img1, hipMemcpyHostToDevice));
+    ctx->n_tables = n_tables;
+    return GCN10_OK;
+}
+
+// ---- per-function kernels -------------------------------------------------
+
+int gcn10_gpu_resample(gcn10_gpu_ctx *ctx, const uint8_t *coarse, int hsx, int hsy,
+                       const int32_t *ci, const int32_t *cj, int W, int rows, uint8_t *out,
+                       gcn10_stream_t stream)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (hsx <= 0 || hsy <= 0 || W < 0 || rows < 0)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_resample: bad shape %dx%d <- %dx%d", W, rows, hsx, hsy);
+    if (W == 0 || rows == 0)
+        return GCN10_OK;
+    if (!coarse || !ci || !cj || !out)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_resample: null pointer");
+    const uint64_t npix = (uint64_t)W * rows;
+    const uint32_t grid = stream_grid(ctx, (npix + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(resample_rows, dim3(grid), dim3(kThreads), 0, as_stream(ctx, stream),
+                       coarse, (uint32_t)hsx, ci, cj, (uint32_t)W, (uint32_t)rows, out);
+    HIP_TRY(hipGetLastError());
+    return GCN10_OK;
+}
+
+int gcn10_gpu_modify_hysogs_data(gcn10_gpu_ctx *ctx, uint8_t *h, size_t npix, int drained,
+                                 gcn10_stream_t stream)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (npix == 0)
+        return GCN10_OK;
+    if (!h)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_modify_hysogs_data: null pointer");
+    size_t head = (16 - (reinterpret_cast<uintptr_t>(h) & 15u)) & 15u;
+    if (head > npix)
+        head = npix;
+    const size_t nvec = (npix - head) / 16;
+    const uint32_t grid = stream_grid(ctx, (nvec + kThreads - 1) / kThreads + 1);
+    hipLaunchKernelGGL(modify_hysogs_kernel, dim3(grid), dim3(kThreads), 0,
+                       as_stream(ctx, stream), h, npix, drained, head, nvec);
+    HIP_TRY(hipGetLastError());
+    return GCN10_OK;
+}
+
+int gcn10_gpu_calculate_cn(gcn10_gpu_ctx *ctx, const uint8_t *esa, const uint8_t *hsg,
+                           size_t npix, int table_index, uint8_t *out, gcn10_stream_t stream)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (ctx->n_tables == 0)
+        return fail(GCN10_E_STATE, "gcn10_gpu_calculate_cn: call gcn10_gpu_set_tables first");
+    if (table_index < 0 || table_index >= ctx->n_tables)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_calculate_cn: table %d not loaded (have %d)",
+                    table_index, ctx->n_tables);
+    if (npix == 0)
+        return GCN10_OK;
+    if (!esa || !hsg || !out)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_calculate_cn: null pointer");
+    const uint8_t *img = ctx->d_lut1 + (size_t)table_index * kLut1Bytes;
+    const bool vec = aligned16(esa) && aligned16(hsg) && aligned16(out);
+    const uint64_t work = vec ? (npix / 16 + kThreads - 1) / kThreads + 1
+                              : (npix + kThreads - 1) / kThreads;
+    const uint32_t grid = stream_grid(ctx, work);
+    if (vec)
+        hipLaunchKernelGGL(calculate_cn_kernel<true>, dim3(grid), dim3(kThreads), 0,
+                           as_stream(ctx, stream), esa, hsg, npix, img, out);
+    else
+        hipLaunchKernelGGL(calculate_cn_kernel<false>, dim3(grid), dim3(kThreads), 0,
+                           as_stream(ctx, stream), esa, hsg, npix, img, out);
+    HIP_TRY(hipGetLastError());
+    return GCN10_OK;
+}
+
+// ---- fused block path -----------------------------------------------------
+
+int gcn10_gpu_prepare_tile(gcn10_gpu_ctx *ctx, const uint8_t *coarse, int hsx, int hsy,
+                           const int32_t *ci, int W, gcn10_stream_t stream)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (hsx <= 0 || hsy <= 0 || W <= 0)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_prepare_tile: bad shape W=%d soil=%dx%d", W, hsx, hsy);
+    if (!coarse || !ci)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_prepare_tile: null pointer");
+    // rows padded to a multiple of 16 plus one extra group so that any 16-byte
+    // read starting below W stays inside the row
+    const uint32_t stride = (((uint32_t)W + 15u) & ~15u) + 16u;
+    const size_t need = (size_t)stride * (size_t)hsy;
+    if (need > ctx->hx_capacity) {
+        // growing the workspace is the one allocation on this path; it happens
+        // once per run for equally sized blocks (sync: the old buffer may be in use)
+        HIP_TRY(hipDeviceSynchronize());
+        if (ctx->d_hx)
+            HIP_TRY(hipFree(ctx->d_hx));
+        ctx->d_hx = nullptr;
+        ctx->hx_capacity = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_hx), need));
+        ctx->hx_capacity = need;
+    }
+    ctx->hx_stride = stride;
+    ctx->hx_W = (uint32_t)W;
+    ctx->hx_rows = (uint32_t)hsy;
+    dim3 grid((stride / 4 + kThreads - 1) / kThreads, (uint32_t)hsy);
+    hipLaunchKernelGGL(expand_x_codes, grid, dim3(kThreads), 0, as_stream(ctx, stream), coarse,
+                       (uint32_t)hsx, (uint32_t)hsy, ci, (uint32_t)W, ctx->d_hx, stride);
+    HIP_TRY(hipGetLastError());
+    return GCN10_OK;
+}
+
+int gcn10_gpu_cn_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, int rows,
+                       const int32_t *cj, unsigned cond_mask, unsigned table_mask,
+                       uint8_t *const out[GCN10_N_RASTERS], gcn10_stream_t stream)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (ctx->n_tables == 0)
+        return fail(GCN10_E_STATE, "gcn10_gpu_cn_strip: call gcn10_gpu_set_tables first");
+    if (!ctx->d_hx || ctx->hx_W == 0)
+        return fail(GCN10_E_STATE, "gcn10_gpu_cn_strip: call gcn10_gpu_prepare_tile first");
+    if (W <= 0 || rows < 0 || (uint32_t)W != ctx->hx_W)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_cn_strip: W=%d rows=%d does not match prepared tile W=%u",
+                    W, rows, ctx->hx_W);
+    if ((uint64_t)W * (uint64_t)rows > 0x7fffffffull)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_cn_strip: strip of %d x %d exceeds 2^31-1 pixels", W, rows);
+    if (cond_mask == 0 || (cond_mask & ~3u))
+        return fail(GCN10_E_INVAL, "gcn10_gpu_cn_strip: cond_mask 0x%x", cond_mask);
+    if (table_mask == 0 || (table_mask >> ctx->n_tables))
+        return fail(GCN10_E_INVAL, "gcn10_gpu_cn_strip: table_mask 0x%x with %d tables loaded",
+                    table_mask, ctx->n_tables);
+    if (rows == 0)
+        return GCN10_OK;
+    if (!esa || !cj || !out)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_cn_strip: null pointer");
+
+    StripParams p;
+    memset(&p, 0, sizeof p);
+    bool all_aligned = aligned16(esa);
+    for (int c = 0; c < 2; c++) {
+        for (int k = 0; k < 9; k++) {
+            const int r = c * 9 + k;
+            if ((cond_mask & (1u << c)) && (table_mask & (1u << k))) {
+                if (!out[r])
+                    return fail(GCN10_E_INVAL, "gcn10_gpu_cn_strip: out[%d] is null but selected", r);
+                p.out[r] = out[r];
+                all_aligned = all_aligned && aligned16(out[r]);
+            }
+        }
+    }
+    p.esa = esa;
+    p.hx = ctx->d_hx;
+    p.cj = cj;
+    p.W = (uint32_t)W;
+    p.rows = (uint32_t)rows;
+    p.npix = (uint32_t)((uint64_t)W * (uint64_t)rows);
+    p.hx_stride = ctx->hx_stride;
+    p.hx_rows = ctx->hx_rows;
+    p.nchunks = (p.npix + kChunk - 1) / kChunk;
+    p.table_mask = table_mask;
+    hipStream_t s = as_stream(ctx, stream);
+    const uint32_t grid = stream_grid(ctx, p.nchunks);
+
+    if (!all_aligned) {
+        p.lut = ctx->d_lut16;
+        const uint32_t g = stream_grid(ctx, ((uint64_t)p.npix + kThreads - 1) / kThreads);
+        hipLaunchKernelGGL(cn_strip_bytes, dim3(g), dim3(kThreads), 0, s, p, cond_mask);
+        ctx->last_kernel = "cn_strip_bytes";
+    }
+    else if (popcount(table_mask) == 1) {
+        p.single_k = (uint32_t)__builtin_ctz(table_mask);
+        p.lut = ctx->d_lut1 + (size_t)p.single_k * kLut1Bytes;
+        switch (cond_mask) {
+        case 1: hipLaunchKernelGGL(cn_strip_lut1<1>, dim3(grid), dim3(kThreads), 0, s, p); break;
+        case 2: hipLaunchKernelGGL(cn_strip_lut1<2>, dim3(grid), dim3(kThreads), 0, s, p); break;
+        default: hipLaunchKernelGGL(cn_strip_lut1<3>, dim3(grid), dim3(kThreads), 0, s, p); break;
+        }
+        ctx->last_kernel = "cn_strip_lut1";
+    }
+    else {
+        p.lut = ctx->d_lut16;
+        const bool all = table_mask == 0x1ffu;
+        switch (cond_mask) {
+        case 1:
+            if (all) hipLaunchKernelGGL((cn_strip_lut16<1, true>), dim3(grid), dim3(kThreads), 0, s, p);
+            else hipLaunchKernelGGL((cn_strip_lut16<1, false>), dim3(grid), dim3(kThreads), 0, s, p);
+            break;
+        case 2:
+            if (all) hipLaunchKernelGGL((cn_strip_lut16<2, true>), dim3(grid), dim3(kThreads), 0, s, p);
+            else hipLaunchKernelGGL((cn_strip_lut16<2, false>), dim3(grid), dim3(kThreads), 0, s, p);
+            break;
+        default:
+            if (all) hipLaunchKernelGGL((cn_strip_lut16<3, true>), dim3(grid), dim3(kThreads), 0, s, p);
+            else hipLaunchKernelGGL((cn_strip_lut16<3, false>), dim3(grid), dim3(kThreads), 0, s, p);
+            break;
+        }
+        ctx->last_kernel = "cn_strip_lut16";
+    }
+    HIP_TRY(hipGetLastError());
+    return GCN10_OK;
+}
+
+size_t gcn10_gpu_strip_algorithmic_bytes(int W, int rows, int hsx, int hsy, unsigned cond_mask,
+                                         unsigned table_mask)
+{
+    if (W <= 0 || rows <= 0)
+        return 0;
+    const size_t n_out = (size_t)popcount(cond_mask & 3u) * (size_t)popcount(table_mask & 0x1ffu);
+    // 1 B landcover read + n_out B written per pixel,
+    // + the coarse soil window once, + the int32 index maps once.
+    return (size_t)W * rows * (1 + n_out) + (size_t)(hsx > 0 ? hsx : 0) * (hsy > 0 ? hsy : 0) +
+           4 * ((size_t)W + rows);
+}
+
+const char *gcn10_gpu_last_kernel_name(gcn10_gpu_ctx *ctx)
+{
+    return ctx ? ctx->last_kernel : "";
+}
+
+}  // extern "C"

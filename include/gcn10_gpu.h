@@ -1,0 +1,177 @@
+/*
+ * gcn10_gpu.h -- C ABI of the MI355X (gfx950) curve-number engine.
+ *
+ * This is the drop-in boundary for gcn10's per-pixel path.  The reference has
+ * no FFI layer; its seam is the set of C prototypes in src/global.h:47-71 and
+ * the static kernels of src/cn.c.  Each entry point below names the reference
+ * code it replaces.  Plain C types only: no HIP or torch types cross this line.
+ * A stream or event is an opaque pointer (a hipStream_t / hipEvent_t inside);
+ * passing NULL as a stream means "the context's own main stream".
+ *
+ * All functions returning int give 0 on success or a negative GCN10_E_* code;
+ * gcn10_gpu_last_error() returns the calling thread's last message.  The
+ * reference's functions are void and log-then-return or MPI_Abort
+ * (src/cn.c:156-160, 25); the host driver maps these codes back to that
+ * behaviour.
+ *
+ * Threading: a context belongs to one GPU and is used by one host thread at a
+ * time (the reference runs one thread per rank, src/main.c:171-176).
+ *
+ * There is no CPU fallback behind this ABI: every call needs a live gfx950
+ * device, and gcn10_gpu_init() fails loudly without one.
+ */
+#ifndef GCN10_GPU_H
+#define GCN10_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCN10_GPU_ABI_VERSION 1
+
+enum {
+    GCN10_OK = 0,
+    GCN10_E_INVAL = -1,     /* bad argument (null pointer, size, mask)        */
+    GCN10_E_HIP = -2,       /* a HIP runtime call failed; see last_error      */
+    GCN10_E_NOMEM = -3,     /* device or pinned-host allocation failed        */
+    GCN10_E_STATE = -4,     /* call order: tables / tile not prepared         */
+    GCN10_E_NODEVICE = -5   /* no gfx950 device visible                       */
+};
+
+/* Raster order of the 18 outputs of one block: index = cond*9 + hc*3 + arc,
+ * cond in {drained, undrained}, hc in {p, f, g}, arc in {i, ii, iii}
+ * -- the loop order of src/cn.c:145-147, 236-259. */
+#define GCN10_N_TABLES 9
+#define GCN10_N_CONDS 2
+#define GCN10_N_RASTERS 18
+#define GCN10_COND_DRAINED 1u       /* cond_mask bit for conds[0] (src/cn.c:145) */
+#define GCN10_COND_UNDRAINED 2u     /* cond_mask bit for conds[1]                */
+#define GCN10_NODATA 255            /* src/cn.c:38, 289                          */
+
+typedef struct gcn10_gpu_ctx gcn10_gpu_ctx;
+typedef void *gcn10_stream_t;
+typedef void *gcn10_event_t;
+
+/* ---- life cycle -------------------------------------------------------- */
+
+int gcn10_gpu_abi_version(void);
+/* Number of visible HIP devices (0 when there is none or the runtime fails). */
+int gcn10_gpu_device_count(void);
+/* One context per GPU.  Replaces the per-rank process state of the reference
+ * (MPI_Init + rank, src/main.c:80-82): "rank" becomes the device index. */
+int gcn10_gpu_init(int device, gcn10_gpu_ctx **ctx);
+void gcn10_gpu_destroy(gcn10_gpu_ctx *ctx);
+const char *gcn10_gpu_last_error(void);
+/* Fills name[cap] with the device name and returns CU count, or <0. */
+int gcn10_gpu_device_info(gcn10_gpu_ctx *ctx, char *name, size_t cap,
+                          size_t *hbm_bytes);
+
+/* ---- memory, streams, events ------------------------------------------ */
+/* The reference mallocs every raster on the host (src/raster.c:169,
+ * src/cn.c:209,264,278).  Here rasters live in HBM; the host stages them
+ * through pinned buffers (replaces GDALRasterIO's destination buffer,
+ * src/raster.c:176-178, 217-219). */
+
+int gcn10_gpu_malloc(gcn10_gpu_ctx *ctx, size_t bytes, void **dptr);
+int gcn10_gpu_free(gcn10_gpu_ctx *ctx, void *dptr);
+int gcn10_gpu_host_alloc(gcn10_gpu_ctx *ctx, size_t bytes, void **hptr);
+int gcn10_gpu_host_free(gcn10_gpu_ctx *ctx, void *hptr);
+/* Asynchronous on `stream`; the host buffer must be pinned for real overlap. */
+int gcn10_gpu_memcpy_h2d(gcn10_gpu_ctx *ctx, void *dst_dev, const void *src_host,
+                         size_t bytes, gcn10_stream_t stream);
+int gcn10_gpu_memcpy_d2h(gcn10_gpu_ctx *ctx, void *dst_host, const void *src_dev,
+                         size_t bytes, gcn10_stream_t stream);
+int gcn10_gpu_memset(gcn10_gpu_ctx *ctx, void *dptr, int value, size_t bytes,
+                     gcn10_stream_t stream);
+
+int gcn10_gpu_stream_create(gcn10_gpu_ctx *ctx, gcn10_stream_t *stream);
+int gcn10_gpu_stream_destroy(gcn10_gpu_ctx *ctx, gcn10_stream_t stream);
+int gcn10_gpu_stream_sync(gcn10_gpu_ctx *ctx, gcn10_stream_t stream);
+int gcn10_gpu_device_sync(gcn10_gpu_ctx *ctx);
+int gcn10_gpu_event_create(gcn10_gpu_ctx *ctx, gcn10_event_t *ev);
+int gcn10_gpu_event_destroy(gcn10_gpu_ctx *ctx, gcn10_event_t ev);
+int gcn10_gpu_event_record(gcn10_gpu_ctx *ctx, gcn10_event_t ev, gcn10_stream_t stream);
+int gcn10_gpu_event_sync(gcn10_gpu_ctx *ctx, gcn10_event_t ev);
+/* Makes `stream` wait for `ev` (device-side; the host does not block). */
+int gcn10_gpu_stream_wait_event(gcn10_gpu_ctx *ctx, gcn10_stream_t stream, gcn10_event_t ev);
+int gcn10_gpu_event_elapsed_ms(gcn10_gpu_ctx *ctx, gcn10_event_t start,
+                               gcn10_event_t stop, float *ms);
+
+/* ---- lookup tables ----------------------------------------------------- */
+/* Replaces the hand-off `int table[256][5]` from load_lookup_table() to
+ * calculate_cn() (src/cn.c:148, 261, 290).  `tables` is n_tables consecutive
+ * reference-format tables, i.e. int[n_tables][256][5] exactly as
+ * load_lookup_table fills them (255 = nodata).  The engine folds the
+ * `cn_value < 255 ? (uint8_t)cn_value : keep 255` rule of src/cn.c:125-128
+ * into byte tables once, and keeps them on the device until replaced.
+ * 1 <= n_tables <= 9. */
+int gcn10_gpu_set_tables(gcn10_gpu_ctx *ctx, const int *tables, int n_tables);
+
+/* ---- per-function kernels (one reference function each) ---------------- */
+
+/* src/cn.c:218-232, the resample loop, with its separable index arithmetic
+ * hoisted to the host: ci[W] and cj[rows] are the clamped coarse column / row
+ * of every fine column / row (gcn10_build_index_maps in gcn10_host.h computes
+ * them in the reference's exact fp64 order).  out[y*W+x] =
+ * coarse[cj[y]*hsx+ci[x]].  All pointers are device pointers. */
+int gcn10_gpu_resample(gcn10_gpu_ctx *ctx, const uint8_t *coarse, int hsx, int hsy,
+                       const int32_t *ci, const int32_t *cj, int W, int rows,
+                       uint8_t *out, gcn10_stream_t stream);
+
+/* src/cn.c:88-111 modify_hysogs_data(), in place on a device buffer;
+ * drained != 0 <=> cond == "drained". */
+int gcn10_gpu_modify_hysogs_data(gcn10_gpu_ctx *ctx, uint8_t *h, size_t npix,
+                                 int drained, gcn10_stream_t stream);
+
+/* src/cn.c:114-131 calculate_cn() on a raster the reference pre-fills with 255
+ * (src/cn.c:289): out[i] = (hsg[i] < 5 && T[esa[i]][hsg[i]] < 255) ?
+ * (uint8_t)T[esa[i]][hsg[i]] : 255, T = table `table_index` of set_tables. */
+int gcn10_gpu_calculate_cn(gcn10_gpu_ctx *ctx, const uint8_t *esa,
+                           const uint8_t *hsg, size_t npix, int table_index,
+                           uint8_t *out, gcn10_stream_t stream);
+
+/* ---- fused block path --------------------------------------------------- */
+/* Replaces the body of process_block() between load_raster and save_raster
+ * (src/cn.c:205-290): resample + memcpy + modify_hysogs_data + memset +
+ * calculate_cn for every (cond, hc, arc), in one pass over the landcover.
+ *
+ * gcn10_gpu_prepare_tile: once per block.  Expands the coarse soil window
+ * along x only (one row of W bytes per coarse row, kept in a device workspace
+ * that stays L2 / Infinity-Cache resident) -- the x half of src/cn.c:218-232.
+ *
+ * gcn10_gpu_cn_strip: any number of times per block, one row strip each
+ * (rows y0 .. y0+rows of the block; `esa` and every out[] pointer address the
+ * first pixel of the strip; cj points at the strip's first entry, i.e.
+ * &cj_block[y0]).  For every selected raster r = cond*9 + k it writes
+ *     h = coarse[cj[y]*hsx + ci[x]];  s = remap_cond(h)   (src/cn.c:88-111)
+ *     out[r][y*W+x] = s < 5 ? T8[k][esa[y*W+x]][s] : 255  (src/cn.c:114-131)
+ * cond_mask: GCN10_COND_* bits; table_mask: bit k selects table k (< n_tables).
+ * out[] has GCN10_N_RASTERS entries (host array of device pointers); entries
+ * of unselected rasters are ignored and may be NULL.  Strips of one block may
+ * be issued on different streams once prepare_tile's stream work is ordered
+ * before them (event or sync). */
+int gcn10_gpu_prepare_tile(gcn10_gpu_ctx *ctx, const uint8_t *coarse, int hsx,
+                           int hsy, const int32_t *ci, int W,
+                           gcn10_stream_t stream);
+int gcn10_gpu_cn_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, int rows,
+                       const int32_t *cj, unsigned cond_mask, unsigned table_mask,
+                       uint8_t *const out[GCN10_N_RASTERS], gcn10_stream_t stream);
+
+/* Bytes the dominant kernel (cn_strip) must move per launch by the algorithm:
+ * W*rows*(1 + n_selected_rasters) + the x-expanded soil rows it reads once.
+ * Used by the benchmark for the roofline figure ("algorithmic
+ * bytes"). */
+size_t gcn10_gpu_strip_algorithmic_bytes(int W, int rows, int hsx, int hsy,
+                                         unsigned cond_mask, unsigned table_mask);
+
+/* Name of the variant of the strip kernel the last cn_strip call launched
+ * (for profiles and bench records). */
+const char *gcn10_gpu_last_kernel_name(gcn10_gpu_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCN10_GPU_H */

@@ -109,9 +109,10 @@ def calculate_cn(esa: np.ndarray, hsg: np.ndarray, table: np.ndarray) -> np.ndar
 
 def _c_round(v: np.ndarray) -> np.ndarray:
     """C99 ``round``: nearest, ties away from zero (numpy's round is ties-even)."""
-    t = np.trunc(v)
-    frac = np.abs(v - t)            # exact for doubles
-    return t + np.where(frac >= 0.5, np.copysign(1.0, v), 0.0)
+    with np.errstate(invalid="ignore"):
+        t = np.trunc(v)
+        frac = np.abs(v - t)        # exact for doubles; inf - inf = nan stays put
+        return t + np.where(frac >= 0.5, np.copysign(1.0, v), 0.0)
 
 
 def _to_int_x86(v: np.ndarray) -> np.ndarray:
