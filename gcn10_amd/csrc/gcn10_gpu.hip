@@ -697,7 +697,7 @@ int gcn10_gpu_device_info(gcn10_gpu_ctx *ctx, char *name, size_t cap, size_t *hb
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
     if (name && cap)
-        snprintf(name, cap, "%s (%s)", prop.name, prop.gcnArchName);
+        snprintf(name, cap, "%s (%s)", prop.name[0] ? prop.name : "AMD GPU", prop.gcnArchName);
     if (hbm_bytes)
         *hbm_bytes = prop.totalGlobalMem;
     return prop.multiProcessorCount;

@@ -50,7 +50,9 @@ def main():
     from oracle import cn_oracle_c as oc
     oc.build()
     ncores = len(os.sched_getaffinity(0))
-    procs = a.procs or ncores
+    # a one-GPU box's CPU share is 16 cores; more workers than that would time
+    # other tenants' cores (and 256 x 4 rasters in flight is a lot of RAM)
+    procs = a.procs or min(ncores, int(os.environ.get("GCN10_CPU_BASELINE_PROCS", "16")))
     n_out = bin(a.cond_mask & 3).count("1") * bin(a.table_mask & 0x1FF).count("1")
     px = a.width * a.rows
     res = {}

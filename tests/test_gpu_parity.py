@@ -19,8 +19,9 @@ from tests.util import make_block, random_tables
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture
 def eng9(engine, tables):
+    """The shared engine with the nine shipped tables loaded (other tests load their own)."""
     engine.set_tables(tables)
     return engine
 
@@ -177,7 +178,7 @@ def test_argument_errors(eng9):
 # ---- BASELINE.json full size: 36000 x 36000 --------------------------------
 
 @pytest.fixture(scope="module")
-def full_tile(eng9, tables):
+def full_tile(engine, tables):
     """One 36000^2 block resident on the GPU with all 18 rasters computed once."""
     H = W = 36000
     rng = np.random.default_rng(1)
@@ -192,7 +193,8 @@ def full_tile(eng9, tables):
     gt = [0.0, 3.0 / W, 0.0, 3.0, 0.0, -3.0 / W]
     sgt = [0.0, 3.0 / 1440, 0.0, 3.0, 0.0, -3.0 / 1440]
     ci, cj = host.build_index_maps(gt, sgt, W, H, 1440, 1440)
-    e = eng9
+    e = engine
+    e.set_tables(tables)
     bufs = dict(esa=e.upload(esa), coarse=e.upload(coarse), ci=e.upload(ci), cj=e.upload(cj))
     outs = [e.alloc(H * W) for _ in range(18)]
     e.prepare_tile(bufs["coarse"].ptr, 1440, 1440, bufs["ci"].ptr, W)
