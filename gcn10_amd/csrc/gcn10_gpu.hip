@@ -89,6 +89,7 @@ struct StripParams {
     uint32_t nchunks;
     uint32_t table_mask;
     uint32_t single_k;      // table index for the single-table variant
+    uint32_t xcd_slabs;     // 1: each XCD streams a contiguous eighth of the strip
 };
 
 // soil code byte: low nibble = plane for "drained", high nibble = "undrained".
@@ -141,9 +142,14 @@ __device__ __forceinline__ uint32_t gather_byte0(uint32_t a, uint32_t b, uint32_
     return t0 | t1;
 }
 
-__device__ __forceinline__ u32x4 load16_aligned(const uint8_t *p)
+__device__ __forceinline__ u32x4 load16_aligned_nt(const uint8_t *p)
 {
     return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+}
+
+__device__ __forceinline__ u32x4 load16_aligned(const uint8_t *p)
+{
+    return *reinterpret_cast<const u32x4 *>(p);
 }
 
 __device__ __forceinline__ u32x4 load16_any(const uint8_t *p)
@@ -154,9 +160,13 @@ __device__ __forceinline__ u32x4 load16_any(const uint8_t *p)
     return *reinterpret_cast<const u32x4_u *>(p);
 }
 
+template <bool NT = true>
 __device__ __forceinline__ void store16(uint8_t *p, u32x4 v)
 {
-    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
+    if (NT)
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
+    else
+        *reinterpret_cast<u32x4 *>(p) = v;
 }
 
 // Coarse soil row of strip row y.  cj comes from the caller (host-built, already
@@ -166,6 +176,23 @@ __device__ __forceinline__ uint32_t soil_row(const StripParams &p, uint32_t y)
 {
     const uint32_t r = (uint32_t)p.cj[y];
     return r < p.hx_rows ? r : p.hx_rows - 1u;
+}
+
+__device__ __forceinline__ uint32_t clamp_row(const StripParams &p, int32_t r)
+{
+    const uint32_t u = (uint32_t)r;
+    return u < p.hx_rows ? u : p.hx_rows - 1u;
+}
+
+// cj[i] for a wave-uniform i through the scalar data cache (s_load_dword):
+// constant-address-space loads with a uniform address select SMEM, which has
+// its own counter (lgkmcnt) and does not queue behind vector memory traffic.
+// cj is written by a copy that completed before this kernel started.
+__device__ __forceinline__ int32_t scalar_load_i32(const int32_t *base, uint32_t i)
+{
+    typedef const int32_t __attribute__((address_space(4))) *const_ptr_t;
+    const_ptr_t cp = (const_ptr_t)(uintptr_t)base;
+    return cp[__builtin_amdgcn_readfirstlane(i)];
 }
 
 // Split a flat strip index into (row, column).  `wave_base` is uniform over
@@ -192,11 +219,11 @@ __device__ __forceinline__ void flat_to_xy(uint32_t wave_base, uint32_t lane_off
 // XCDs (b and b+8 share one L2), so give each XCD a contiguous slab of the
 // strip: the x-expanded soil rows a slab re-reads then stay in that XCD's L2.
 __device__ __forceinline__ uint32_t first_chunk(uint32_t nchunks, uint32_t &step,
-                                                uint32_t &end)
+                                                uint32_t &end, bool xcd_slabs)
 {
     uint32_t nb = gridDim.x;
     uint32_t b = blockIdx.x;
-    if (nb % 8u == 0u && nchunks >= nb) {
+    if (xcd_slabs && nb % 8u == 0u && nchunks >= nb) {
         uint32_t xcd = b & 7u;
         uint32_t per = (nchunks + 7u) / 8u;
         uint32_t lo = xcd * per;
@@ -211,19 +238,71 @@ __device__ __forceinline__ uint32_t first_chunk(uint32_t nchunks, uint32_t &step
 }
 
 // ------------------------------------------------------------------------
-// cn_strip, all-tables variant: one 16-byte LDS row per (soil plane, class)
-// holds the CN of all nine tables, so a pixel costs one ds_read_b128 per
-// drainage condition whatever the number of rasters written.
+// cn_strip: the fused block kernel.
+//
+// KIND = kLut16 (all-tables): one 16-byte LDS row per (soil plane, class) holds
+//   the CN of all nine tables, so a pixel costs one ds_read_b128 per drainage
+//   condition whatever the number of rasters written; 4x4 byte transposes
+//   (v_perm_b32) turn "9 values of one pixel" into "4 pixels of one raster".
+// KIND = kLut1 (single table, BASELINE config 2): 2-3 B/px of HBM traffic, so
+//   the pixel rate is ~8x higher and the LDS work per pixel must be one byte
+//   read, not a 16-byte row.
+// ILP  = 4096-px sub-chunks a workgroup handles per loop trip; all their loads
+//   are issued before any is consumed (more HBM requests in flight per wave).
+// NT   = nontemporal landcover loads and raster stores.
 // ------------------------------------------------------------------------
-template <int COND_MASK, bool ALL_TABLES>
-__global__ __launch_bounds__(kThreads) void cn_strip_lut16(const StripParams p)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t lut[kLut16Bytes];
+enum { kLut16 = 0, kLut1 = 1 };
 
-    {
+template <int KIND>
+__device__ __forceinline__ void slow_pixels(const StripParams &p, const uint8_t *lut,
+                                            uint32_t cond_mask, uint32_t tmask, uint32_t i0,
+                                            uint32_t y, uint32_t x0)
+{
+    // strip tail, or a lane whose 16 pixels straddle a row end
+    uint32_t yy = y, xx = x0;
+    for (uint32_t q = 0; q < (uint32_t)kPxPerLane; q++) {
+        const uint32_t i = i0 + q;
+        if (i >= p.npix)
+            break;
+        const uint32_t lc = p.esa[i];
+        const uint32_t cd = p.hx[(size_t)soil_row(p, yy) * p.hx_stride + xx];
+        for (int c = 0; c < 2; c++) {
+            if (!(cond_mask & (1u << c)))
+                continue;
+            const uint32_t s = (cd >> (4 * c)) & 0xfu;
+            if (KIND == kLut16) {
+                const uint8_t *row = lut + s * (uint32_t)kPlane16 + lc * 16u;
+                for (int k = 0; k < 9; k++)
+                    if (tmask & (1u << k))
+                        p.out[c * 9 + k][i] = row[k];
+            }
+            else {
+                p.out[c * 9 + p.single_k][i] = lut[s * (uint32_t)kPlane1 + lc];
+            }
+        }
+        if (++xx == p.W) {
+            xx = 0;
+            yy++;
+        }
+    }
+}
+
+template <int KIND, int COND_MASK, bool ALL_TABLES, int ILP, bool NT>
+__global__ __launch_bounds__(kThreads) void cn_strip_kernel(const StripParams p)
+{
+    constexpr int kLutBytes = KIND == kLut16 ? kLut16Bytes : kLut1Bytes;
+    __shared__ __attribute__((aligned(16))) uint8_t lut[kLutBytes];
+
+    if (KIND == kLut16) {
         const u32x4 *src = reinterpret_cast<const u32x4 *>(p.lut);
         u32x4 *dst = reinterpret_cast<u32x4 *>(lut);
-        for (int i = threadIdx.x; i < kLut16Bytes / 16; i += kThreads)
+        for (int i = threadIdx.x; i < kLutBytes / 16; i += kThreads)
+            dst[i] = src[i];
+    }
+    else {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(p.lut);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(lut);
+        for (int i = threadIdx.x; i < kLutBytes / 4; i += kThreads)
             dst[i] = src[i];
     }
     __syncthreads();
@@ -232,155 +311,120 @@ __global__ __launch_bounds__(kThreads) void cn_strip_lut16(const StripParams p)
     const uint32_t wave_off = (threadIdx.x >> 6) * 64u * kPxPerLane;
     const uint32_t tmask = ALL_TABLES ? 0x1ffu : p.table_mask;
 
+    // p.nchunks counts groups of ILP sub-chunks here
     uint32_t step, end;
-    for (uint32_t chunk = first_chunk(p.nchunks, step, end); chunk < end; chunk += step) {
-        const uint32_t wave_base = chunk * (uint32_t)kChunk + wave_off;
-        const uint32_t i0 = wave_base + lane_off;
-        if (i0 >= p.npix)
-            continue;
-        uint32_t y, x0;
-        flat_to_xy(wave_base, lane_off, p.W, y, x0);
+    for (uint32_t chunk = first_chunk(p.nchunks, step, end, p.xcd_slabs != 0); chunk < end;
+         chunk += step) {
+        uint32_t i0[ILP], y[ILP], x0[ILP];
+        bool live[ILP], fast[ILP];
+        u32x4 e16[ILP], c16[ILP];
+        uint32_t row[ILP];
 
-        if (i0 + kPxPerLane <= p.npix && x0 + kPxPerLane <= p.W) {
-            // ---- fast path: 16 pixels of one row ----
-            const u32x4 e16 = load16_aligned(p.esa + i0);
-            const uint32_t r = soil_row(p, y);
-            const u32x4 c16 = load16_any(p.hx + (size_t)r * p.hx_stride + x0);
+        // ---- phase 1: addresses.  The coarse row of a wave's first pixel (and
+        // of the next raster row) comes through the scalar cache, so the soil
+        // load below does not wait behind a vector load of cj ----
+#pragma unroll
+        for (int u = 0; u < ILP; u++) {
+            const uint32_t wave_base = __builtin_amdgcn_readfirstlane(
+                (chunk * ILP + u) * (uint32_t)kChunk + wave_off);
+            i0[u] = wave_base + lane_off;
+            live[u] = i0[u] < p.npix;
+            fast[u] = false;
+            y[u] = x0[u] = 0;
+            row[u] = 0;
+            if (wave_base < p.npix) {           // wave-uniform
+                const uint32_t yb = wave_base / p.W;
+                const uint32_t xb = wave_base - yb * p.W;
+                const uint32_t yn = yb + 1u < p.rows ? yb + 1u : yb;
+                const uint32_t r0 = clamp_row(p, scalar_load_i32(p.cj, yb));
+                const uint32_t r1 = clamp_row(p, scalar_load_i32(p.cj, yn));
+                uint32_t xx = xb + lane_off, yy = yb;
+                row[u] = r0;
+                if (xx >= p.W) {
+                    xx -= p.W;
+                    yy = yb + 1u;
+                    row[u] = r1;
+                    if (xx >= p.W) {            // rows narrower than a wave's span
+                        const uint32_t q = xx / p.W;
+                        yy += q;
+                        xx -= q * p.W;
+                        if (live[u])
+                            row[u] = soil_row(p, yy);
+                    }
+                }
+                y[u] = yy;
+                x0[u] = xx;
+                fast[u] = live[u] && i0[u] + kPxPerLane <= p.npix && xx + kPxPerLane <= p.W;
+            }
+        }
+        // ---- phase 2: all global loads of the trip, back to back ----
+#pragma unroll
+        for (int u = 0; u < ILP; u++) {
+            if (fast[u]) {
+                e16[u] = NT ? load16_aligned_nt(p.esa + i0[u]) : load16_aligned(p.esa + i0[u]);
+                c16[u] = load16_any(p.hx + (size_t)row[u] * p.hx_stride + x0[u]);
+            }
+        }
 
+        // ---- phase 3: table gathers + stores ----
+#pragma unroll
+        for (int u = 0; u < ILP; u++) {
+            if (!live[u])
+                continue;
+            if (!fast[u]) {
+                slow_pixels<KIND>(p, lut, COND_MASK, tmask, i0[u], y[u], x0[u]);
+                continue;
+            }
 #pragma unroll
             for (int c = 0; c < 2; c++) {
                 if (!(COND_MASK & (1 << c)))
                     continue;
-                uint32_t acc[9][4];
+                if (KIND == kLut16) {
+                    uint32_t acc[9][4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t e = e16[j];
-                    const uint32_t cd = c16[j];
-                    u32x4 row[4];
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t e = e16[u][j];
+                        const uint32_t cd = c16[u][j];
+                        u32x4 r4[4];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const uint32_t lc16 = q == 0 ? (e << 4) & 0xff0u
-                                                     : (e >> (8 * q - 4)) & 0xff0u;
-                        const uint32_t s = (cd >> (8 * q + 4 * c)) & 0xfu;
-                        const uint32_t addr = s * (uint32_t)kPlane16 + lc16;
-                        row[q] = *reinterpret_cast<const u32x4 *>(lut + addr);
+                        for (int q = 0; q < 4; q++) {
+                            const uint32_t lc16 = q == 0 ? (e << 4) & 0xff0u
+                                                         : (e >> (8 * q - 4)) & 0xff0u;
+                            const uint32_t s = (cd >> (8 * q + 4 * c)) & 0xfu;
+                            const uint32_t addr = s * (uint32_t)kPlane16 + lc16;
+                            r4[q] = *reinterpret_cast<const u32x4 *>(lut + addr);
+                        }
+                        transpose4x4(r4[0][0], r4[1][0], r4[2][0], r4[3][0], acc[0][j], acc[1][j],
+                                     acc[2][j], acc[3][j]);
+                        transpose4x4(r4[0][1], r4[1][1], r4[2][1], r4[3][1], acc[4][j], acc[5][j],
+                                     acc[6][j], acc[7][j]);
+                        acc[8][j] = gather_byte0(r4[0][2], r4[1][2], r4[2][2], r4[3][2]);
                     }
-                    transpose4x4(row[0][0], row[1][0], row[2][0], row[3][0],
-                                 acc[0][j], acc[1][j], acc[2][j], acc[3][j]);
-                    transpose4x4(row[0][1], row[1][1], row[2][1], row[3][1],
-                                 acc[4][j], acc[5][j], acc[6][j], acc[7][j]);
-                    acc[8][j] = gather_byte0(row[0][2], row[1][2], row[2][2], row[3][2]);
-                }
 #pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    if (tmask & (1u << k)) {
-                        u32x4 v = {acc[k][0], acc[k][1], acc[k][2], acc[k][3]};
-                        store16(p.out[c * 9 + k] + i0, v);
+                    for (int k = 0; k < 9; k++) {
+                        if (tmask & (1u << k)) {
+                            u32x4 v = {acc[k][0], acc[k][1], acc[k][2], acc[k][3]};
+                            store16<NT>(p.out[c * 9 + k] + i0[u], v);
+                        }
                     }
                 }
-            }
-        }
-        else {
-            // ---- slow path: strip tail or a lane that straddles rows ----
-            uint32_t yy = y, xx = x0;
-            for (uint32_t q = 0; q < (uint32_t)kPxPerLane; q++) {
-                const uint32_t i = i0 + q;
-                if (i >= p.npix)
-                    break;
-                const uint32_t lc = p.esa[i];
-                const uint32_t cd = p.hx[(size_t)soil_row(p, yy) * p.hx_stride + xx];
-                for (int c = 0; c < 2; c++) {
-                    if (!(COND_MASK & (1 << c)))
-                        continue;
-                    const uint32_t s = (cd >> (4 * c)) & 0xfu;
-                    const uint8_t *row = lut + s * (uint32_t)kPlane16 + lc * 16u;
-                    for (int k = 0; k < 9; k++)
-                        if (tmask & (1u << k))
-                            p.out[c * 9 + k][i] = row[k];
-                }
-                if (++xx == p.W) {
-                    xx = 0;
-                    yy++;
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------
-// cn_strip, single-table variant (BASELINE config 2: one lookup, 2-3 B/px of
-// HBM traffic, so the pixel rate is ~8x the all-tables kernel's and the LDS
-// work per pixel must be one byte read, not a 16-byte row).
-// ------------------------------------------------------------------------
-template <int COND_MASK>
-__global__ __launch_bounds__(kThreads) void cn_strip_lut1(const StripParams p)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t lut[kLut1Bytes];
-
-    {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(p.lut);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(lut);
-        for (int i = threadIdx.x; i < kLut1Bytes / 4; i += kThreads)
-            dst[i] = src[i];
-    }
-    __syncthreads();
-
-    const uint32_t lane_off = (threadIdx.x & 63u) * kPxPerLane;
-    const uint32_t wave_off = (threadIdx.x >> 6) * 64u * kPxPerLane;
-    const uint32_t k = p.single_k;
-
-    uint32_t step, end;
-    for (uint32_t chunk = first_chunk(p.nchunks, step, end); chunk < end; chunk += step) {
-        const uint32_t wave_base = chunk * (uint32_t)kChunk + wave_off;
-        const uint32_t i0 = wave_base + lane_off;
-        if (i0 >= p.npix)
-            continue;
-        uint32_t y, x0;
-        flat_to_xy(wave_base, lane_off, p.W, y, x0);
-
-        if (i0 + kPxPerLane <= p.npix && x0 + kPxPerLane <= p.W) {
-            const u32x4 e16 = load16_aligned(p.esa + i0);
-            const uint32_t r = soil_row(p, y);
-            const u32x4 c16 = load16_any(p.hx + (size_t)r * p.hx_stride + x0);
+                else {
+                    u32x4 v;
 #pragma unroll
-            for (int c = 0; c < 2; c++) {
-                if (!(COND_MASK & (1 << c)))
-                    continue;
-                u32x4 v;
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t e = e16[u][j];
+                        const uint32_t cd = c16[u][j];
+                        uint32_t w = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t e = e16[j];
-                    const uint32_t cd = c16[j];
-                    uint32_t w = 0;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const uint32_t lc = (e >> (8 * q)) & 0xffu;
-                        const uint32_t s = (cd >> (8 * q + 4 * c)) & 0xfu;
-                        const uint32_t b = lut[s * (uint32_t)kPlane1 + lc];
-                        w |= b << (8 * q);
+                        for (int q = 0; q < 4; q++) {
+                            const uint32_t lc = (e >> (8 * q)) & 0xffu;
+                            const uint32_t s = (cd >> (8 * q + 4 * c)) & 0xfu;
+                            const uint32_t b = lut[s * (uint32_t)kPlane1 + lc];
+                            w |= b << (8 * q);
+                        }
+                        v[j] = w;
                     }
-                    v[j] = w;
-                }
-                store16(p.out[c * 9 + k] + i0, v);
-            }
-        }
-        else {
-            uint32_t yy = y, xx = x0;
-            for (uint32_t q = 0; q < (uint32_t)kPxPerLane; q++) {
-                const uint32_t i = i0 + q;
-                if (i >= p.npix)
-                    break;
-                const uint32_t lc = p.esa[i];
-                const uint32_t cd = p.hx[(size_t)soil_row(p, yy) * p.hx_stride + xx];
-                for (int c = 0; c < 2; c++) {
-                    if (!(COND_MASK & (1 << c)))
-                        continue;
-                    const uint32_t s = (cd >> (4 * c)) & 0xfu;
-                    p.out[c * 9 + k][i] = lut[s * (uint32_t)kPlane1 + lc];
-                }
-                if (++xx == p.W) {
-                    xx = 0;
-                    yy++;
+                    store16<NT>(p.out[c * 9 + p.single_k] + i0[u], v);
                 }
             }
         }
@@ -418,32 +462,58 @@ __global__ __launch_bounds__(kThreads) void cn_strip_bytes(const StripParams p,
 }
 
 // ------------------------------------------------------------------------
-// x-expansion of the coarse soil window (the x half of src/cn.c:218-232).
-// CODE = true : write soil_code(h) for the fused path (hx workspace)
-// CODE = false: write h itself (gcn10_gpu_resample, row picked by cj too)
+// x-expansion of the coarse soil window (the x half of src/cn.c:218-232):
+// hx[r][x] = soil_code(coarse[r][ci[x]]) for every coarse row r.
 // ------------------------------------------------------------------------
+template <bool VEC>
 __global__ __launch_bounds__(kThreads) void expand_x_codes(const uint8_t *coarse,
                                                            uint32_t hsx, uint32_t hsy,
                                                            const int32_t *ci, uint32_t W,
                                                            uint8_t *hx, uint32_t hx_stride)
 {
-    const uint32_t x = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
+    // one thread = 16 consecutive fine columns of one coarse row: 4 index loads
+    // (dwordx4 when ci is 16-byte aligned), 16 byte gathers that hit L1/L2 (a
+    // coarse row is ~1.4 KB), one 16-byte store
+    const uint32_t x = (blockIdx.x * blockDim.x + threadIdx.x) * 16u;
     const uint32_t r = blockIdx.y;
     if (x >= hx_stride)
         return;
     const uint8_t *row = coarse + (size_t)r * hsx;
-    uint32_t w = 0;
+    const uint8_t pad = (uint8_t)(kInvalidPlane | (kInvalidPlane << 4));
+    u32x4 o;
+    if (VEC && x + 16u <= W) {
+        const u32x4 *civ = reinterpret_cast<const u32x4 *>(ci + x);
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        // columns past W are padding: give them the "invalid" code
-        uint8_t code = (uint8_t)(kInvalidPlane | (kInvalidPlane << 4));
-        if (x + q < W) {
-            const uint32_t cx = (uint32_t)ci[x + q];
-            code = soil_code(row[cx < hsx ? cx : hsx - 1u]);
+        for (int j = 0; j < 4; j++) {
+            const u32x4 c4 = civ[j];
+            uint32_t w = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t cx = c4[q];
+                w |= (uint32_t)soil_code(row[cx < hsx ? cx : hsx - 1u]) << (8 * q);
+            }
+            o[j] = w;
         }
-        w |= (uint32_t)code << (8 * q);
     }
-    *reinterpret_cast<uint32_t *>(hx + (size_t)r * hx_stride + x) = w;
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                // columns past W are padding: give them the "invalid" code
+                uint8_t code = pad;
+                const uint32_t xx = x + 4 * j + q;
+                if (xx < W) {
+                    const uint32_t cx = (uint32_t)ci[xx];
+                    code = soil_code(row[cx < hsx ? cx : hsx - 1u]);
+                }
+                w |= (uint32_t)code << (8 * q);
+            }
+            o[j] = w;
+        }
+    }
+    *reinterpret_cast<u32x4 *>(hx + (size_t)r * hx_stride + x) = o;
 }
 
 __global__ __launch_bounds__(kThreads) void resample_rows(const uint8_t *coarse,
@@ -524,8 +594,8 @@ __global__ __launch_bounds__(kThreads) void calculate_cn_kernel(const uint8_t *e
     const size_t nvec = VEC ? npix / 16 : 0;
     if (VEC) {
         for (size_t v = tid; v < nvec; v += stride) {
-            const u32x4 e16 = load16_aligned(esa + v * 16);
-            const u32x4 h16 = load16_aligned(hsg + v * 16);
+            const u32x4 e16 = load16_aligned_nt(esa + v * 16);
+            const u32x4 h16 = load16_aligned_nt(hsg + v * 16);
             u32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -548,6 +618,46 @@ __global__ __launch_bounds__(kThreads) void calculate_cn_kernel(const uint8_t *e
         s = s < 5u ? s : (uint32_t)kInvalidPlane;
         out[i] = lut[s * (uint32_t)kPlane1 + lc];
     }
+}
+
+typedef void (*strip_kernel_t)(const StripParams);
+
+template <int KIND, int ILP, bool NT>
+strip_kernel_t pick_by_mask(unsigned cond_mask, bool all)
+{
+    // the single-table kernel ignores ALL_TABLES: instantiate it once
+    constexpr bool kSingle = KIND == kLut1;
+    switch (cond_mask) {
+    case 1:
+        return (all || kSingle) ? cn_strip_kernel<KIND, 1, true, ILP, NT>
+                                : cn_strip_kernel<KIND, 1, kSingle, ILP, NT>;
+    case 2:
+        return (all || kSingle) ? cn_strip_kernel<KIND, 2, true, ILP, NT>
+                                : cn_strip_kernel<KIND, 2, kSingle, ILP, NT>;
+    default:
+        return (all || kSingle) ? cn_strip_kernel<KIND, 3, true, ILP, NT>
+                                : cn_strip_kernel<KIND, 3, kSingle, ILP, NT>;
+    }
+}
+
+template <int KIND>
+strip_kernel_t pick_by_ilp(unsigned cond_mask, bool all, int ilp, bool nt)
+{
+    switch (ilp) {
+    case 1: return nt ? pick_by_mask<KIND, 1, true>(cond_mask, all) : pick_by_mask<KIND, 1, false>(cond_mask, all);
+    case 2: return nt ? pick_by_mask<KIND, 2, true>(cond_mask, all) : pick_by_mask<KIND, 2, false>(cond_mask, all);
+    case 4:
+        if (KIND == kLut1)
+            return nt ? pick_by_mask<kLut1, 4, true>(cond_mask, all) : pick_by_mask<kLut1, 4, false>(cond_mask, all);
+        return nullptr;
+    default: return nullptr;
+    }
+}
+
+strip_kernel_t pick_strip_kernel(bool single, unsigned cond_mask, bool all, int ilp, bool nt)
+{
+    return single ? pick_by_ilp<kLut1>(cond_mask, all, ilp, nt)
+                  : pick_by_ilp<kLut16>(cond_mask, all, ilp, nt);
 }
 
 inline bool aligned16(const void *p)
@@ -578,7 +688,12 @@ struct gcn10_gpu_ctx {
     uint32_t hx_W = 0;
     uint32_t hx_rows = 0;
     const char *last_kernel = "";
+    // tuning knobs (gcn10_gpu_set_option); defaults = the round-1 measured best
     int grid_blocks_per_cu = 8;
+    int ilp16 = 1;          // sub-chunks per loop trip, all-tables kernel (1, 2)
+    int ilp1 = 1;           // same, single-table kernel (1, 2, 4)
+    int nontemporal = 1;
+    int xcd_slabs = 1;
 };
 
 namespace {
@@ -1037,9 +1152,13 @@ int gcn10_gpu_prepare_tile(gcn10_gpu_ctx *ctx, const uint8_t *coarse, int hsx, i
     ctx->hx_stride = stride;
     ctx->hx_W = (uint32_t)W;
     ctx->hx_rows = (uint32_t)hsy;
-    dim3 grid((stride / 4 + kThreads - 1) / kThreads, (uint32_t)hsy);
-    hipLaunchKernelGGL(expand_x_codes, grid, dim3(kThreads), 0, as_stream(ctx, stream), coarse,
-                       (uint32_t)hsx, (uint32_t)hsy, ci, (uint32_t)W, ctx->d_hx, stride);
+    dim3 grid((stride / 16 + kThreads - 1) / kThreads, (uint32_t)hsy);
+    if (aligned16(ci))
+        hipLaunchKernelGGL(expand_x_codes<true>, grid, dim3(kThreads), 0, as_stream(ctx, stream),
+                           coarse, (uint32_t)hsx, (uint32_t)hsy, ci, (uint32_t)W, ctx->d_hx, stride);
+    else
+        hipLaunchKernelGGL(expand_x_codes<false>, grid, dim3(kThreads), 0, as_stream(ctx, stream),
+                           coarse, (uint32_t)hsx, (uint32_t)hsy, ci, (uint32_t)W, ctx->d_hx, stride);
     HIP_TRY(hipGetLastError());
     return GCN10_OK;
 }
@@ -1095,42 +1214,33 @@ int gcn10_gpu_cn_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, int rows,
     p.nchunks = (p.npix + kChunk - 1) / kChunk;
     p.table_mask = table_mask;
     hipStream_t s = as_stream(ctx, stream);
-    const uint32_t grid = stream_grid(ctx, p.nchunks);
 
+    p.xcd_slabs = (uint32_t)ctx->xcd_slabs;
     if (!all_aligned) {
         p.lut = ctx->d_lut16;
         const uint32_t g = stream_grid(ctx, ((uint64_t)p.npix + kThreads - 1) / kThreads);
         hipLaunchKernelGGL(cn_strip_bytes, dim3(g), dim3(kThreads), 0, s, p, cond_mask);
         ctx->last_kernel = "cn_strip_bytes";
     }
-    else if (popcount(table_mask) == 1) {
-        p.single_k = (uint32_t)__builtin_ctz(table_mask);
-        p.lut = ctx->d_lut1 + (size_t)p.single_k * kLut1Bytes;
-        switch (cond_mask) {
-        case 1: hipLaunchKernelGGL(cn_strip_lut1<1>, dim3(grid), dim3(kThreads), 0, s, p); break;
-        case 2: hipLaunchKernelGGL(cn_strip_lut1<2>, dim3(grid), dim3(kThreads), 0, s, p); break;
-        default: hipLaunchKernelGGL(cn_strip_lut1<3>, dim3(grid), dim3(kThreads), 0, s, p); break;
-        }
-        ctx->last_kernel = "cn_strip_lut1";
-    }
     else {
-        p.lut = ctx->d_lut16;
+        const bool single = popcount(table_mask) == 1;
         const bool all = table_mask == 0x1ffu;
-        switch (cond_mask) {
-        case 1:
-            if (all) hipLaunchKernelGGL((cn_strip_lut16<1, true>), dim3(grid), dim3(kThreads), 0, s, p);
-            else hipLaunchKernelGGL((cn_strip_lut16<1, false>), dim3(grid), dim3(kThreads), 0, s, p);
-            break;
-        case 2:
-            if (all) hipLaunchKernelGGL((cn_strip_lut16<2, true>), dim3(grid), dim3(kThreads), 0, s, p);
-            else hipLaunchKernelGGL((cn_strip_lut16<2, false>), dim3(grid), dim3(kThreads), 0, s, p);
-            break;
-        default:
-            if (all) hipLaunchKernelGGL((cn_strip_lut16<3, true>), dim3(grid), dim3(kThreads), 0, s, p);
-            else hipLaunchKernelGGL((cn_strip_lut16<3, false>), dim3(grid), dim3(kThreads), 0, s, p);
-            break;
+        const int ilp = single ? ctx->ilp1 : ctx->ilp16;
+        const bool nt = ctx->nontemporal != 0;
+        if (single) {
+            p.single_k = (uint32_t)__builtin_ctz(table_mask);
+            p.lut = ctx->d_lut1 + (size_t)p.single_k * kLut1Bytes;
         }
-        ctx->last_kernel = "cn_strip_lut16";
+        else {
+            p.lut = ctx->d_lut16;
+        }
+        p.nchunks = (p.nchunks + (uint32_t)ilp - 1) / (uint32_t)ilp;    // groups of ILP sub-chunks
+        const uint32_t grid = stream_grid(ctx, p.nchunks);
+        strip_kernel_t fn = pick_strip_kernel(single, cond_mask, all, ilp, nt);
+        if (!fn)
+            return fail(GCN10_E_INVAL, "gcn10_gpu_cn_strip: no kernel for ilp=%d", ilp);
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), 0, s, p);
+        ctx->last_kernel = single ? "cn_strip_lut1" : "cn_strip_lut16";
     }
     HIP_TRY(hipGetLastError());
     return GCN10_OK;
@@ -1146,6 +1256,25 @@ size_t gcn10_gpu_strip_algorithmic_bytes(int W, int rows, int hsx, int hsy, unsi
     // + the coarse soil window once, + the int32 index maps once.
     return (size_t)W * rows * (1 + n_out) + (size_t)(hsx > 0 ? hsx : 0) * (hsy > 0 ? hsy : 0) +
            4 * ((size_t)W + rows);
+}
+
+int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value)
+{
+    if (!ctx || !name)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_set_option: null argument");
+    if (!strcmp(name, "grid_blocks_per_cu") && value >= 1 && value <= 64)
+        ctx->grid_blocks_per_cu = value;
+    else if (!strcmp(name, "ilp16") && (value == 1 || value == 2))
+        ctx->ilp16 = value;
+    else if (!strcmp(name, "ilp1") && (value == 1 || value == 2 || value == 4))
+        ctx->ilp1 = value;
+    else if (!strcmp(name, "nontemporal") && (value == 0 || value == 1))
+        ctx->nontemporal = value;
+    else if (!strcmp(name, "xcd_slabs") && (value == 0 || value == 1))
+        ctx->xcd_slabs = value;
+    else
+        return fail(GCN10_E_INVAL, "gcn10_gpu_set_option: unknown option or bad value: %s=%d", name, value);
+    return GCN10_OK;
 }
 
 const char *gcn10_gpu_last_kernel_name(gcn10_gpu_ctx *ctx)

@@ -1,0 +1,115 @@
+/* config.c -- key=value run configuration.
+ *
+ * Same file grammar and the same five required keys as the reference's
+ * parse_config() (/root/reference/src/config.c:44-114): '#' comment lines,
+ * lines without '=' ignored, unknown keys ignored, surrounding whitespace
+ * trimmed, 511-byte lines.  Existing gcn10 config files work unchanged; a few
+ * optional keys steer the GPU pipeline.
+ */
+#include "gcn10_host.h"
+
+#include <ctype.h>
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static char *strip(char *s)
+{
+    char *e;
+
+    while (*s && isspace((unsigned char)*s))
+        s++;
+    e = s + strlen(s);
+    while (e > s && isspace((unsigned char)e[-1]))
+        e--;
+    *e = '\0';
+    return s;
+}
+
+static int set_str(char **slot, const char *val)
+{
+    char *copy = strdup(val);
+
+    if (!copy)
+        return -1;
+    free(*slot);        /* a repeated key: the last one wins, as in the reference */
+    *slot = copy;
+    return 0;
+}
+
+int gcn10_config_parse(const char *path, gcn10_config *cfg, char *err, size_t errcap)
+{
+    char line[512];                                     /* src/config.c:47 */
+    FILE *f;
+
+    memset(cfg, 0, sizeof *cfg);
+    f = fopen(path, "r");
+    if (!f) {
+        snprintf(err, errcap, "cannot open config '%s'", path);     /* src/config.c:52 */
+        return -1;
+    }
+    while (fgets(line, sizeof line, f)) {
+        char *p = strip(line);
+        char *eq, *key, *val;
+        int rc = 0;
+
+        if (*p == '\0' || *p == '#')
+            continue;
+        eq = strchr(p, '=');
+        if (!eq)
+            continue;
+        *eq = '\0';
+        key = strip(p);
+        val = strip(eq + 1);
+
+        if (!strcmp(key, "hysogs_data_path"))
+            rc = set_str(&cfg->hysogs_data_path, val);
+        else if (!strcmp(key, "esa_data_path"))
+            rc = set_str(&cfg->esa_data_path, val);
+        else if (!strcmp(key, "blocks_shp_path"))
+            rc = set_str(&cfg->blocks_shp_path, val);
+        else if (!strcmp(key, "lookup_table_path"))
+            rc = set_str(&cfg->lookup_table_path, val);
+        else if (!strcmp(key, "log_dir"))
+            rc = set_str(&cfg->log_dir, val);
+        else if (!strcmp(key, "esa_tile_dir"))
+            rc = set_str(&cfg->esa_tile_dir, val);
+        else if (!strcmp(key, "gpus"))
+            cfg->gpus = atoi(val);
+        else if (!strcmp(key, "strip_rows"))
+            cfg->strip_rows = atoi(val);
+        else if (!strcmp(key, "io_threads"))
+            cfg->io_threads = atoi(val);
+        else if (!strcmp(key, "deflate_level"))
+            cfg->deflate_level = atoi(val);
+        if (rc != 0) {
+            fclose(f);
+            snprintf(err, errcap, "malloc failed for %s", key);     /* src/config.c:71 */
+            gcn10_config_free(cfg);
+            return -1;
+        }
+    }
+    fclose(f);
+
+    if (!cfg->hysogs_data_path || !cfg->esa_data_path || !cfg->blocks_shp_path ||
+        !cfg->lookup_table_path || !cfg->log_dir) {
+        snprintf(err, errcap,                                       /* src/config.c:109-111 */
+                 "missing one of: hysogs_data_path, esa_data_path,\n"
+                 "blocks_shp_path, lookup_table_path, log_dir");
+        gcn10_config_free(cfg);
+        return -2;
+    }
+    return 0;
+}
+
+void gcn10_config_free(gcn10_config *cfg)
+{
+    free(cfg->hysogs_data_path);
+    free(cfg->esa_data_path);
+    free(cfg->blocks_shp_path);
+    free(cfg->lookup_table_path);
+    free(cfg->log_dir);
+    free(cfg->esa_tile_dir);
+    memset(cfg, 0, sizeof *cfg);
+}

@@ -1,0 +1,1004 @@
+/* tiff.c -- GeoTIFF reader and tiled-DEFLATE GeoTIFF writer without GDAL/libtiff.
+ *
+ * Replaces what the reference gets from GDAL in load_raster() / save_raster()
+ * (/root/reference/src/raster.c:106-227) for the file kinds this program meets:
+ *   read : 8-bit single-band (or pixel-interleaved, band 1 taken) TIFF, classic
+ *          or BigTIFF, either byte order, strips or tiles, compression none /
+ *          LZW (5) / Adobe DEFLATE (8, 32946) / PackBits (32773), predictor 1|2,
+ *          georeferenced by ModelPixelScale + ModelTiepoint or ModelTransformation;
+ *   write: GTiff, Byte, 1 band, COMPRESS=DEFLATE, TILED=YES (256 x 256 tiles),
+ *          the creation options of src/raster.c:204-209, with the input's
+ *          GeoKey tags copied so the projection is the landcover's
+ *          (src/raster.c:212-214).  No NoData tag (the reference sets none).
+ * Format sources: TIFF 6.0 (1992), BigTIFF design note, GeoTIFF 1.0 / OGC 19-008r4.
+ * File *bytes* are not a parity target (GDAL's encoder is third party); decoded
+ * pixels and geotransform are.
+ */
+#include "gcn10_host.h"
+#include "host_internal.h"
+
+#include <errno.h>
+#include <fcntl.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include <zlib.h>
+
+/* ------------------------------------------------------------------------ */
+/* reader                                                                    */
+/* ------------------------------------------------------------------------ */
+
+enum { T_BYTE = 1, T_ASCII = 2, T_SHORT = 3, T_LONG = 4, T_RATIONAL = 5, T_SBYTE = 6,
+       T_UNDEF = 7, T_SSHORT = 8, T_SLONG = 9, T_SRATIONAL = 10, T_FLOAT = 11,
+       T_DOUBLE = 12, T_IFD = 13, T_LONG8 = 16, T_SLONG8 = 17, T_IFD8 = 18 };
+
+struct gcn10_tiff {
+    int fd;
+    bool big, swap;
+    uint32_t width, height;
+    uint16_t bps, spp, compression, predictor, planar;
+    bool tiled;
+    uint32_t cw, ch;            /* chunk (tile or strip) width / height */
+    uint32_t across, down;      /* chunks per row / column */
+    uint64_t *offsets, *counts;
+    uint64_t n_chunks;
+    double gt[6];
+    gcn10_georef georef;
+};
+
+static size_t type_size(unsigned t)
+{
+    switch (t) {
+    case T_BYTE: case T_ASCII: case T_SBYTE: case T_UNDEF: return 1;
+    case T_SHORT: case T_SSHORT: return 2;
+    case T_LONG: case T_SLONG: case T_FLOAT: case T_IFD: return 4;
+    case T_RATIONAL: case T_SRATIONAL: case T_DOUBLE: case T_LONG8: case T_SLONG8: case T_IFD8: return 8;
+    default: return 0;
+    }
+}
+
+static uint64_t rd(const unsigned char *p, int n, bool swap)
+{
+    uint64_t v = 0;
+
+    if (swap)           /* file is big endian */
+        for (int i = 0; i < n; i++)
+            v = (v << 8) | p[i];
+    else
+        for (int i = n - 1; i >= 0; i--)
+            v = (v << 8) | p[i];
+    return v;
+}
+
+static int pread_all(int fd, void *buf, size_t n, uint64_t off)
+{
+    unsigned char *p = buf;
+
+    while (n) {
+        ssize_t r = pread(fd, p, n, (off_t)off);
+
+        if (r < 0 && errno == EINTR)
+            continue;
+        if (r <= 0)
+            return -1;
+        p += r;
+        off += (uint64_t)r;
+        n -= (size_t)r;
+    }
+    return 0;
+}
+
+/* values of one directory entry as raw bytes (malloc'd), file byte order */
+static unsigned char *entry_bytes(struct gcn10_tiff *t, const unsigned char *e, unsigned type,
+                                  uint64_t count, size_t *nbytes)
+{
+    size_t ts = type_size(type);
+    size_t inl = t->big ? 8 : 4;
+    const unsigned char *valp = e + (t->big ? 12 : 8);
+    unsigned char *buf;
+
+    if (!ts || count > (1ull << 31) / ts)
+        return NULL;
+    *nbytes = (size_t)(ts * count);
+    buf = malloc(*nbytes ? *nbytes : 1);
+    if (!buf)
+        return NULL;
+    if (*nbytes <= inl) {
+        memcpy(buf, valp, *nbytes);
+    }
+    else {
+        uint64_t off = rd(valp, (int)inl, t->swap);
+
+        if (pread_all(t->fd, buf, *nbytes, off) != 0) {
+            free(buf);
+            return NULL;
+        }
+    }
+    return buf;
+}
+
+static uint64_t *entry_u64(struct gcn10_tiff *t, const unsigned char *e, unsigned type, uint64_t count)
+{
+    size_t nb = 0, ts = type_size(type);
+    unsigned char *raw = entry_bytes(t, e, type, count, &nb);
+    uint64_t *out;
+
+    if (!raw)
+        return NULL;
+    out = malloc((size_t)(count ? count : 1) * sizeof *out);
+    if (out)
+        for (uint64_t i = 0; i < count; i++)
+            out[i] = rd(raw + i * ts, (int)ts, t->swap);
+    free(raw);
+    return out;
+}
+
+static double *entry_f64(struct gcn10_tiff *t, const unsigned char *e, unsigned type, uint64_t count)
+{
+    size_t nb = 0;
+    unsigned char *raw;
+    double *out;
+
+    if (type != T_DOUBLE)
+        return NULL;
+    raw = entry_bytes(t, e, type, count, &nb);
+    if (!raw)
+        return NULL;
+    out = malloc((size_t)(count ? count : 1) * sizeof *out);
+    if (out)
+        for (uint64_t i = 0; i < count; i++) {
+            uint64_t v = rd(raw + i * 8, 8, t->swap);
+
+            memcpy(&out[i], &v, 8);
+        }
+    free(raw);
+    return out;
+}
+
+void gcn10_tiff_close_reader(struct gcn10_tiff *t)
+{
+    if (!t)
+        return;
+    if (t->fd >= 0)
+        close(t->fd);
+    free(t->offsets);
+    free(t->counts);
+    free(t->georef.geokeys);
+    free(t->georef.geodoubles);
+    free(t->georef.geoascii);
+    free(t);
+}
+
+struct gcn10_tiff *gcn10_tiff_open_reader(const char *path, char *err, size_t errcap)
+{
+    struct gcn10_tiff *t = calloc(1, sizeof *t);
+    unsigned char hdr[16], *dir = NULL;
+    uint64_t ifd, nent;
+    size_t esz;
+    uint32_t rows_per_strip = 0, tw = 0, th = 0;
+    double *scale = NULL, *tie = NULL, *xform = NULL;
+    uint64_t n_scale = 0, n_tie = 0, n_xform = 0;
+    bool have_off = false, have_cnt = false;
+
+    if (!t) {
+        snprintf(err, errcap, "out of memory for raster %s", path);
+        return NULL;
+    }
+    t->fd = open(path, O_RDONLY);
+    if (t->fd < 0 || pread_all(t->fd, hdr, 8, 0) != 0) {
+        snprintf(err, errcap, "gdal open failed: %s", path);        /* src/raster.c:121 */
+        goto fail;
+    }
+    if (hdr[0] == 'I' && hdr[1] == 'I')
+        t->swap = false;
+    else if (hdr[0] == 'M' && hdr[1] == 'M')
+        t->swap = true;
+    else {
+        snprintf(err, errcap, "gdal open failed: %s (not a TIFF)", path);
+        goto fail;
+    }
+    {
+        unsigned magic = (unsigned)rd(hdr + 2, 2, t->swap);
+
+        if (magic == 42) {
+            ifd = rd(hdr + 4, 4, t->swap);
+        }
+        else if (magic == 43) {
+            t->big = true;
+            if (pread_all(t->fd, hdr, 16, 0) != 0)
+                goto badfile;
+            ifd = rd(hdr + 8, 8, t->swap);
+        }
+        else {
+            goto badfile;
+        }
+    }
+    {
+        unsigned char cnt[8];
+        int cn = t->big ? 8 : 2;
+
+        if (pread_all(t->fd, cnt, (size_t)cn, ifd) != 0)
+            goto badfile;
+        nent = rd(cnt, cn, t->swap);
+        esz = t->big ? 20 : 12;
+        if (nent == 0 || nent > 4096)
+            goto badfile;
+        dir = malloc((size_t)nent * esz);
+        if (!dir || pread_all(t->fd, dir, (size_t)nent * esz, ifd + (uint64_t)cn) != 0)
+            goto badfile;
+    }
+    t->bps = 1;
+    t->spp = 1;
+    t->compression = 1;
+    t->predictor = 1;
+    t->planar = 1;
+    for (uint64_t i = 0; i < nent; i++) {
+        const unsigned char *e = dir + i * esz;
+        unsigned tag = (unsigned)rd(e, 2, t->swap);
+        unsigned type = (unsigned)rd(e + 2, 2, t->swap);
+        uint64_t count = t->big ? rd(e + 4, 8, t->swap) : rd(e + 4, 4, t->swap);
+        uint64_t *v = NULL;
+
+        switch (tag) {
+        case 256: case 257: case 258: case 259: case 277: case 278: case 284: case 317:
+        case 322: case 323:
+            v = entry_u64(t, e, type, count);
+            if (!v || count < 1) {
+                free(v);
+                goto badfile;
+            }
+            if (tag == 256) t->width = (uint32_t)v[0];
+            else if (tag == 257) t->height = (uint32_t)v[0];
+            else if (tag == 258) t->bps = (uint16_t)v[0];
+            else if (tag == 259) t->compression = (uint16_t)v[0];
+            else if (tag == 277) t->spp = (uint16_t)v[0];
+            else if (tag == 278) rows_per_strip = (uint32_t)v[0];
+            else if (tag == 284) t->planar = (uint16_t)v[0];
+            else if (tag == 317) t->predictor = (uint16_t)v[0];
+            else if (tag == 322) tw = (uint32_t)v[0];
+            else if (tag == 323) th = (uint32_t)v[0];
+            free(v);
+            break;
+        case 273: case 324:         /* StripOffsets / TileOffsets */
+            free(t->offsets);
+            t->offsets = entry_u64(t, e, type, count);
+            t->n_chunks = count;
+            have_off = t->offsets != NULL;
+            if (tag == 324)
+                t->tiled = true;
+            break;
+        case 279: case 325:         /* StripByteCounts / TileByteCounts */
+            free(t->counts);
+            t->counts = entry_u64(t, e, type, count);
+            have_cnt = t->counts != NULL;
+            break;
+        case 33550:
+            scale = entry_f64(t, e, type, count);
+            n_scale = count;
+            break;
+        case 33922:
+            tie = entry_f64(t, e, type, count);
+            n_tie = count;
+            break;
+        case 34264:
+            xform = entry_f64(t, e, type, count);
+            n_xform = count;
+            break;
+        case 34735:
+            v = entry_u64(t, e, type, count);
+            if (v) {
+                t->georef.geokeys = malloc((size_t)(count ? count : 1) * sizeof(uint16_t));
+                if (t->georef.geokeys) {
+                    for (uint64_t k = 0; k < count; k++)
+                        t->georef.geokeys[k] = (uint16_t)v[k];
+                    t->georef.n_geokeys = (int)count;
+                }
+                free(v);
+            }
+            break;
+        case 34736:
+            t->georef.geodoubles = entry_f64(t, e, type, count);
+            t->georef.n_geodoubles = t->georef.geodoubles ? (int)count : 0;
+            break;
+        case 34737: {
+            size_t nb = 0;
+            unsigned char *raw = entry_bytes(t, e, T_ASCII, count, &nb);
+
+            if (raw) {
+                t->georef.geoascii = malloc(nb + 1);
+                if (t->georef.geoascii) {
+                    memcpy(t->georef.geoascii, raw, nb);
+                    t->georef.geoascii[nb] = '\0';
+                }
+                free(raw);
+            }
+            break;
+        }
+        default:
+            break;
+        }
+    }
+    free(dir);
+    dir = NULL;
+
+    if (!t->width || !t->height || !have_off || !have_cnt)
+        goto badfile;
+    if (t->bps != 8) {
+        snprintf(err, errcap, "gdal open failed: %s (%u bits per sample; only Byte rasters are supported)",
+                 path, t->bps);
+        goto fail;
+    }
+    if (t->planar != 1 && t->spp != 1) {
+        /* band-sequential: band 1 is the first n_chunks / spp chunks */
+        t->n_chunks /= t->spp;
+        t->spp = 1;
+    }
+    if (t->tiled) {
+        if (!tw || !th)
+            goto badfile;
+        t->cw = tw;
+        t->ch = th;
+    }
+    else {
+        t->cw = t->width;
+        t->ch = rows_per_strip && rows_per_strip < t->height ? rows_per_strip : t->height;
+    }
+    t->across = (t->width + t->cw - 1) / t->cw;
+    t->down = (t->height + t->ch - 1) / t->ch;
+    if ((uint64_t)t->across * t->down > t->n_chunks)
+        goto badfile;
+    switch (t->compression) {
+    case 1: case 5: case 8: case 32946: case 32773:
+        break;
+    default:
+        snprintf(err, errcap, "gdal open failed: %s (TIFF compression %u not supported)", path,
+                 t->compression);
+        goto fail;
+    }
+
+    /* geotransform in GDAL order {x0, dx, rx, y0, ry, dy} */
+    t->gt[0] = 0; t->gt[1] = 1; t->gt[2] = 0; t->gt[3] = 0; t->gt[4] = 0; t->gt[5] = 1;
+    if (xform && n_xform >= 16) {
+        t->gt[0] = xform[3]; t->gt[1] = xform[0]; t->gt[2] = xform[1];
+        t->gt[3] = xform[7]; t->gt[4] = xform[4]; t->gt[5] = xform[5];
+    }
+    else if (scale && n_scale >= 2 && tie && n_tie >= 6) {
+        /* GDAL: origin = tiepoint world - tiepoint pixel * scale; north-up */
+        t->gt[1] = scale[0];
+        t->gt[5] = -scale[1];
+        t->gt[0] = tie[3] - tie[0] * scale[0];
+        t->gt[3] = tie[4] + tie[1] * scale[1];
+    }
+    /* RasterPixelIsPoint (GTRasterTypeGeoKey 1025 = 2) shifts by half a pixel, as GDAL does */
+    if (t->georef.geokeys && t->georef.n_geokeys >= 4) {
+        int nk = t->georef.geokeys[3];
+
+        for (int k = 0; k < nk && 4 + 4 * k + 3 < t->georef.n_geokeys; k++) {
+            const uint16_t *key = t->georef.geokeys + 4 + 4 * k;
+
+            if (key[0] == 1025 && key[1] == 0 && key[3] == 2) {
+                t->gt[0] -= 0.5 * t->gt[1] + 0.5 * t->gt[2];
+                t->gt[3] -= 0.5 * t->gt[4] + 0.5 * t->gt[5];
+            }
+        }
+    }
+    free(scale);
+    free(tie);
+    free(xform);
+    return t;
+
+badfile:
+    snprintf(err, errcap, "gdal open failed: %s (unreadable or unsupported TIFF structure)", path);
+fail:
+    free(dir);
+    free(scale);
+    free(tie);
+    free(xform);
+    gcn10_tiff_close_reader(t);
+    return NULL;
+}
+
+void gcn10_tiff_reader_info(const struct gcn10_tiff *t, int *xsize, int *ysize, double gt[6])
+{
+    *xsize = (int)t->width;
+    *ysize = (int)t->height;
+    memcpy(gt, t->gt, sizeof t->gt);
+}
+
+const gcn10_georef *gcn10_tiff_reader_georef(const struct gcn10_tiff *t)
+{
+    return &t->georef;
+}
+
+/* TIFF LZW (TIFF 6.0 section 13): MSB-first codes of 9..12 bits, ClearCode 256,
+ * EndOfInformation 257, "early change" of the code width. */
+static int lzw_decode(const unsigned char *src, size_t n, unsigned char *dst, size_t cap)
+{
+    enum { CLEAR = 256, EOI = 257, FIRST = 258, MAXC = 4096 };
+    static __thread uint16_t prefix[MAXC];
+    static __thread unsigned char suffix[MAXC], first[MAXC];
+    static __thread uint16_t length[MAXC];
+    uint32_t bits = 0;
+    int nbits = 0, width = 9, next = FIRST, prev = -1;
+    size_t ip = 0, op = 0;
+
+    for (int i = 0; i < 256; i++) {
+        prefix[i] = 0;
+        suffix[i] = first[i] = (unsigned char)i;
+        length[i] = 1;
+    }
+    for (;;) {
+        int code;
+
+        while (nbits < width) {
+            if (ip >= n)
+                return op == cap ? 0 : -1;      /* stream ended without EOI */
+            bits = (bits << 8) | src[ip++];
+            nbits += 8;
+        }
+        code = (int)((bits >> (nbits - width)) & ((1u << width) - 1));
+        nbits -= width;
+        if (code == EOI)
+            break;
+        if (code == CLEAR) {
+            width = 9;
+            next = FIRST;
+            prev = -1;
+            continue;
+        }
+        if (prev < 0) {
+            if (code >= 256 || op >= cap)
+                return op >= cap ? 0 : -1;
+            dst[op++] = (unsigned char)code;
+            prev = code;
+            continue;
+        }
+        {
+            /* the string of `code`; code == next is the KwKwK case: string(prev) + its
+             * own first byte */
+            const bool kwkwk = code == next;
+            size_t full, pos;
+            unsigned char fc;
+            int c;
+
+            if (code > next || (kwkwk && next >= MAXC))
+                return -1;
+            fc = kwkwk ? first[prev] : first[code];
+            full = kwkwk ? (size_t)length[prev] + 1 : (size_t)length[code];
+            pos = full;
+            c = kwkwk ? prev : code;
+            if (kwkwk) {
+                pos--;
+                if (op + pos < cap)
+                    dst[op + pos] = fc;
+            }
+            while (pos > 0) {           /* strings are stored as (prefix, last byte) */
+                pos--;
+                if (op + pos < cap)
+                    dst[op + pos] = suffix[c];
+                c = prefix[c];
+            }
+            op += full;
+            if (next < MAXC) {
+                prefix[next] = (uint16_t)prev;
+                suffix[next] = fc;
+                first[next] = first[prev];
+                length[next] = (uint16_t)(length[prev] + 1);
+                next++;
+                if (next + 1 >= (1 << width) && width < 12)    /* early change */
+                    width++;
+            }
+            prev = code;
+            if (op >= cap)
+                return 0;               /* chunk complete; trailing codes are padding */
+        }
+    }
+    return 0;
+}
+
+static int packbits_decode(const unsigned char *src, size_t n, unsigned char *dst, size_t cap)
+{
+    size_t ip = 0, op = 0;
+
+    while (ip < n && op < cap) {
+        int c = (signed char)src[ip++];
+
+        if (c >= 0) {
+            size_t len = (size_t)c + 1;
+
+            if (ip + len > n)
+                return -1;
+            if (op + len > cap)
+                len = cap - op;
+            memcpy(dst + op, src + ip, len);
+            ip += (size_t)c + 1;
+            op += len;
+        }
+        else if (c != -128) {
+            size_t len = (size_t)(1 - c);
+
+            if (ip >= n)
+                return -1;
+            if (op + len > cap)
+                len = cap - op;
+            memset(dst + op, src[ip++], len);
+            op += len;
+        }
+    }
+    return 0;
+}
+
+/* decodes chunk `idx` into buf (cw*ch*spp bytes; strips may be shorter at the end) */
+static int decode_chunk(struct gcn10_tiff *t, uint64_t idx, unsigned char *buf, size_t rawcap,
+                        unsigned char **scratch, size_t *scratch_cap, uint32_t rows_in_chunk)
+{
+    uint64_t off = t->offsets[idx], cnt = t->counts[idx];
+    size_t want = (size_t)t->cw * rows_in_chunk * t->spp;
+
+    if (want > rawcap)
+        return -1;
+    if (cnt == 0) {                 /* sparse tile: GDAL reads it as zeros */
+        memset(buf, 0, want);
+        return 0;
+    }
+    if (t->compression == 1) {
+        if (cnt < want)
+            return -1;
+        return pread_all(t->fd, buf, want, off);
+    }
+    if (cnt > *scratch_cap) {
+        unsigned char *g = realloc(*scratch, (size_t)cnt);
+
+        if (!g)
+            return -1;
+        *scratch = g;
+        *scratch_cap = (size_t)cnt;
+    }
+    if (pread_all(t->fd, *scratch, (size_t)cnt, off) != 0)
+        return -1;
+    if (t->compression == 8 || t->compression == 32946) {
+        uLongf dl = (uLongf)want;
+        int rc = uncompress(buf, &dl, *scratch, (uLong)cnt);
+
+        /* Z_BUF_ERROR with a full buffer = stream longer than the chunk (padding) */
+        if (rc != Z_OK && !(rc == Z_BUF_ERROR && dl == want))
+            return -1;
+        if (dl < want)
+            memset(buf + dl, 0, want - dl);
+    }
+    else if (t->compression == 5) {
+        if (lzw_decode(*scratch, (size_t)cnt, buf, want) != 0)
+            return -1;
+    }
+    else {
+        if (packbits_decode(*scratch, (size_t)cnt, buf, want) != 0)
+            return -1;
+    }
+    if (t->predictor == 2) {        /* horizontal differencing, per row, per sample */
+        size_t rowb = (size_t)t->cw * t->spp;
+
+        for (uint32_t r = 0; r < rows_in_chunk; r++) {
+            unsigned char *row = buf + (size_t)r * rowb;
+
+            for (size_t i = t->spp; i < rowb; i++)
+                row[i] = (unsigned char)(row[i] + row[i - t->spp]);
+        }
+    }
+    return 0;
+}
+
+int gcn10_tiff_read_window(struct gcn10_tiff *t, int xoff, int yoff, int xcount, int ycount,
+                           uint8_t *dst, size_t dst_stride, char *err, size_t errcap)
+{
+    size_t rawcap = (size_t)t->cw * t->ch * t->spp;
+    unsigned char *raw, *scratch = NULL;
+    size_t scratch_cap = 0;
+    int rc = 0;
+
+    if (xoff < 0 || yoff < 0 || xcount <= 0 || ycount <= 0 ||
+        (uint64_t)xoff + (uint64_t)xcount > t->width || (uint64_t)yoff + (uint64_t)ycount > t->height) {
+        snprintf(err, errcap, "window %d,%d %dx%d outside raster %ux%u", xoff, yoff, xcount, ycount,
+                 t->width, t->height);
+        return -1;
+    }
+    raw = malloc(rawcap ? rawcap : 1);
+    if (!raw) {
+        snprintf(err, errcap, "out of memory reading raster window");
+        return -1;
+    }
+    for (uint32_t cy = (uint32_t)yoff / t->ch; cy <= (uint32_t)(yoff + ycount - 1) / t->ch && !rc; cy++) {
+        uint32_t y_lo = cy * t->ch;
+        uint32_t rows_in_chunk = t->tiled ? t->ch
+                                          : (y_lo + t->ch <= t->height ? t->ch : t->height - y_lo);
+        uint32_t ys = (uint32_t)yoff > y_lo ? (uint32_t)yoff : y_lo;
+        uint32_t ye = (uint32_t)(yoff + ycount) < y_lo + rows_in_chunk ? (uint32_t)(yoff + ycount)
+                                                                       : y_lo + rows_in_chunk;
+
+        for (uint32_t cx = (uint32_t)xoff / t->cw; cx <= (uint32_t)(xoff + xcount - 1) / t->cw; cx++) {
+            uint32_t x_lo = cx * t->cw;
+            uint32_t xs = (uint32_t)xoff > x_lo ? (uint32_t)xoff : x_lo;
+            uint32_t xe = (uint32_t)(xoff + xcount) < x_lo + t->cw ? (uint32_t)(xoff + xcount)
+                                                                   : x_lo + t->cw;
+
+            if (decode_chunk(t, (uint64_t)cy * t->across + cx, raw, rawcap, &scratch, &scratch_cap,
+                             rows_in_chunk) != 0) {
+                snprintf(err, errcap, "gdalrasterio error: cannot decode %s %u,%u",
+                         t->tiled ? "tile" : "strip", cx, cy);
+                rc = -1;
+                break;
+            }
+            for (uint32_t y = ys; y < ye; y++) {
+                const unsigned char *s = raw + ((size_t)(y - y_lo) * t->cw + (xs - x_lo)) * t->spp;
+                uint8_t *d = dst + (size_t)(y - (uint32_t)yoff) * dst_stride + (xs - (uint32_t)xoff);
+
+                if (t->spp == 1) {
+                    memcpy(d, s, xe - xs);
+                }
+                else {
+                    for (uint32_t x = 0; x < xe - xs; x++)
+                        d[x] = s[(size_t)x * t->spp];
+                }
+            }
+        }
+    }
+    free(raw);
+    free(scratch);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------ */
+/* writer                                                                    */
+/* ------------------------------------------------------------------------ */
+
+enum { TILE = 256 };        /* GDAL's default block size for TILED=YES */
+
+struct gcn10_tiff_writer {
+    int fd;
+    char *path;
+    int xsize, ysize, across, down;
+    double gt[6];
+    gcn10_georef georef;        /* deep copy */
+    uint32_t *offsets, *counts;
+    uint64_t pos;               /* append position */
+    pthread_mutex_t mu;
+    bool failed;
+};
+
+static int write_all(int fd, const void *buf, size_t n, uint64_t off)
+{
+    const unsigned char *p = buf;
+
+    while (n) {
+        ssize_t w = pwrite(fd, p, n, (off_t)off);
+
+        if (w < 0 && errno == EINTR)
+            continue;
+        if (w <= 0)
+            return -1;
+        p += w;
+        off += (uint64_t)w;
+        n -= (size_t)w;
+    }
+    return 0;
+}
+
+static void free_georef(gcn10_georef *g)
+{
+    free(g->geokeys);
+    free(g->geodoubles);
+    free(g->geoascii);
+    memset(g, 0, sizeof *g);
+}
+
+static int copy_georef(gcn10_georef *dst, const gcn10_georef *src)
+{
+    /* default: EPSG:4326 geographic, pixel-is-area -- what both inputs of this
+     * program are (README of the reference: "HYSOGs250m_4326", WorldCover) */
+    static const uint16_t wgs84[] = { 1, 1, 0, 3, 1024, 0, 1, 2, 1025, 0, 1, 1, 2048, 0, 1, 4326 };
+
+    memset(dst, 0, sizeof *dst);
+    if (!src || !src->geokeys || src->n_geokeys < 4) {
+        dst->geokeys = malloc(sizeof wgs84);
+        if (!dst->geokeys)
+            return -1;
+        memcpy(dst->geokeys, wgs84, sizeof wgs84);
+        dst->n_geokeys = (int)(sizeof wgs84 / sizeof wgs84[0]);
+        return 0;
+    }
+    dst->geokeys = malloc((size_t)src->n_geokeys * sizeof(uint16_t));
+    if (!dst->geokeys)
+        return -1;
+    memcpy(dst->geokeys, src->geokeys, (size_t)src->n_geokeys * sizeof(uint16_t));
+    dst->n_geokeys = src->n_geokeys;
+    if (src->geodoubles && src->n_geodoubles > 0) {
+        dst->geodoubles = malloc((size_t)src->n_geodoubles * sizeof(double));
+        if (!dst->geodoubles)
+            return -1;
+        memcpy(dst->geodoubles, src->geodoubles, (size_t)src->n_geodoubles * sizeof(double));
+        dst->n_geodoubles = src->n_geodoubles;
+    }
+    if (src->geoascii) {
+        dst->geoascii = strdup(src->geoascii);
+        if (!dst->geoascii)
+            return -1;
+    }
+    return 0;
+}
+
+gcn10_tiff_writer *gcn10_tiff_create(const char *path, int xsize, int ysize, const double gt[6],
+                                     const gcn10_georef *georef, char *err, size_t errcap)
+{
+    static const unsigned char header[8] = { 'I', 'I', 42, 0, 0, 0, 0, 0 };
+    gcn10_tiff_writer *w;
+    size_t nt;
+
+    if (xsize <= 0 || ysize <= 0) {
+        snprintf(err, errcap, "write error: bad raster size %dx%d for %s", xsize, ysize, path);
+        return NULL;
+    }
+    w = calloc(1, sizeof *w);
+    if (!w)
+        goto oom;
+    w->fd = -1;
+    pthread_mutex_init(&w->mu, NULL);
+    w->xsize = xsize;
+    w->ysize = ysize;
+    w->across = (xsize + TILE - 1) / TILE;
+    w->down = (ysize + TILE - 1) / TILE;
+    memcpy(w->gt, gt, sizeof w->gt);
+    nt = (size_t)w->across * (size_t)w->down;
+    w->offsets = calloc(nt, sizeof *w->offsets);
+    w->counts = calloc(nt, sizeof *w->counts);
+    w->path = strdup(path);
+    if (!w->offsets || !w->counts || !w->path || copy_georef(&w->georef, georef) != 0)
+        goto oom;
+    w->fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (w->fd < 0 || write_all(w->fd, header, sizeof header, 0) != 0) {
+        snprintf(err, errcap, "write error: cannot create %s: %s", path, strerror(errno));
+        gcn10_tiff_abort(w);
+        return NULL;
+    }
+    w->pos = sizeof header;
+    return w;
+
+oom:
+    snprintf(err, errcap, "out of memory creating %s", path);
+    if (w)
+        gcn10_tiff_abort(w);
+    return NULL;
+}
+
+int gcn10_tiff_tiles_across(const gcn10_tiff_writer *w)
+{
+    return w->across;
+}
+
+int gcn10_tiff_tiles_down(const gcn10_tiff_writer *w)
+{
+    return w->down;
+}
+
+int gcn10_tiff_put_tile(gcn10_tiff_writer *w, int tx, int ty, const void *zdata, size_t nbytes)
+{
+    int rc = 0;
+    size_t idx;
+
+    if (tx < 0 || ty < 0 || tx >= w->across || ty >= w->down || nbytes == 0)
+        return -1;
+    idx = (size_t)ty * (size_t)w->across + (size_t)tx;
+    pthread_mutex_lock(&w->mu);
+    if (w->pos + nbytes + (1u << 20) > 0xffffffffull) {
+        w->failed = true;           /* classic TIFF offsets are 32 bit */
+        rc = -1;
+    }
+    else if (write_all(w->fd, zdata, nbytes, w->pos) != 0) {
+        w->failed = true;
+        rc = -1;
+    }
+    else {
+        w->offsets[idx] = (uint32_t)w->pos;
+        w->counts[idx] = (uint32_t)nbytes;
+        w->pos += nbytes;
+    }
+    pthread_mutex_unlock(&w->mu);
+    return rc;
+}
+
+static void put16(unsigned char *p, unsigned v)
+{
+    p[0] = (unsigned char)(v & 0xff);
+    p[1] = (unsigned char)(v >> 8);
+}
+
+static void put32(unsigned char *p, uint32_t v)
+{
+    p[0] = (unsigned char)(v & 0xff);
+    p[1] = (unsigned char)((v >> 8) & 0xff);
+    p[2] = (unsigned char)((v >> 16) & 0xff);
+    p[3] = (unsigned char)(v >> 24);
+}
+
+struct dirent_w {
+    unsigned tag, type;
+    uint32_t count;
+    const void *data;       /* little-endian payload */
+    size_t nbytes;
+};
+
+int gcn10_tiff_finish(gcn10_tiff_writer *w, char *err, size_t errcap)
+{
+    size_t nt = (size_t)w->across * (size_t)w->down;
+    double scale[3] = { w->gt[1], -w->gt[5], 0.0 };
+    double tie[6] = { 0, 0, 0, w->gt[0], w->gt[3], 0 };
+    unsigned char s_w[4], s_h[4], s_bps[2], s_comp[2], s_phot[2], s_spp[2], s_plan[2], s_tw[2],
+        s_th[2], s_fmt[2];
+    struct dirent_w ents[20];
+    int ne = 0, rc = -1;
+    unsigned char *dir = NULL;
+    uint64_t data_pos, dir_pos;
+    size_t dirbytes;
+
+    if (w->failed) {
+        snprintf(err, errcap, "write error on %s", w->path);
+        goto done;
+    }
+    for (size_t i = 0; i < nt; i++)
+        if (w->counts[i] == 0) {
+            snprintf(err, errcap, "write error on %s: tile %zu was never written", w->path, i);
+            goto done;
+        }
+    put32(s_w, (uint32_t)w->xsize);
+    put32(s_h, (uint32_t)w->ysize);
+    put16(s_bps, 8);
+    put16(s_comp, 8);           /* COMPRESS=DEFLATE -> Adobe deflate */
+    put16(s_phot, 1);           /* MinIsBlack */
+    put16(s_spp, 1);
+    put16(s_plan, 1);
+    put16(s_tw, TILE);
+    put16(s_th, TILE);
+    put16(s_fmt, 1);            /* unsigned integer */
+#define ENT(tag_, type_, count_, data_, nbytes_) \
+    ents[ne++] = (struct dirent_w){ tag_, type_, (uint32_t)(count_), data_, nbytes_ }
+    ENT(256, T_LONG, 1, s_w, 4);
+    ENT(257, T_LONG, 1, s_h, 4);
+    ENT(258, T_SHORT, 1, s_bps, 2);
+    ENT(259, T_SHORT, 1, s_comp, 2);
+    ENT(262, T_SHORT, 1, s_phot, 2);
+    ENT(277, T_SHORT, 1, s_spp, 2);
+    ENT(284, T_SHORT, 1, s_plan, 2);
+    ENT(322, T_SHORT, 1, s_tw, 2);
+    ENT(323, T_SHORT, 1, s_th, 2);
+    ENT(324, T_LONG, nt, w->offsets, nt * 4);      /* host is little endian (x86-64) */
+    ENT(325, T_LONG, nt, w->counts, nt * 4);
+    ENT(339, T_SHORT, 1, s_fmt, 2);
+    if (w->gt[2] == 0.0 && w->gt[4] == 0.0) {
+        ENT(33550, T_DOUBLE, 3, scale, sizeof scale);
+        ENT(33922, T_DOUBLE, 6, tie, sizeof tie);
+    }
+    ENT(34735, T_SHORT, w->georef.n_geokeys, w->georef.geokeys, (size_t)w->georef.n_geokeys * 2);
+    if (w->georef.geodoubles)
+        ENT(34736, T_DOUBLE, w->georef.n_geodoubles, w->georef.geodoubles,
+            (size_t)w->georef.n_geodoubles * 8);
+    if (w->georef.geoascii)
+        ENT(34737, T_ASCII, strlen(w->georef.geoascii) + 1, w->georef.geoascii,
+            strlen(w->georef.geoascii) + 1);
+#undef ENT
+
+    /* out-of-line payloads first, then the directory, both word aligned */
+    data_pos = (w->pos + 1) & ~1ull;
+    dirbytes = 2 + (size_t)ne * 12 + 4;
+    dir = calloc(1, dirbytes);
+    if (!dir) {
+        snprintf(err, errcap, "out of memory finishing %s", w->path);
+        goto done;
+    }
+    put16(dir, (unsigned)ne);
+    for (int i = 0; i < ne; i++) {
+        unsigned char *e = dir + 2 + i * 12;
+
+        put16(e, ents[i].tag);
+        put16(e + 2, ents[i].type);
+        put32(e + 4, ents[i].count);
+        if (ents[i].nbytes <= 4) {
+            memcpy(e + 8, ents[i].data, ents[i].nbytes);
+        }
+        else {
+            if (data_pos + ents[i].nbytes > 0xffffffffull ||
+                write_all(w->fd, ents[i].data, ents[i].nbytes, data_pos) != 0) {
+                snprintf(err, errcap, "write error on %s", w->path);
+                goto done;
+            }
+            put32(e + 8, (uint32_t)data_pos);
+            data_pos = (data_pos + ents[i].nbytes + 1) & ~1ull;
+        }
+    }
+    dir_pos = data_pos;
+    {
+        unsigned char off[4];
+
+        put32(off, (uint32_t)dir_pos);
+        if (dir_pos + dirbytes > 0xffffffffull || write_all(w->fd, dir, dirbytes, dir_pos) != 0 ||
+            write_all(w->fd, off, 4, 4) != 0) {
+            snprintf(err, errcap, "write error on %s", w->path);
+            goto done;
+        }
+    }
+    rc = 0;
+done:
+    free(dir);
+    if (w->fd >= 0 && close(w->fd) != 0 && rc == 0) {
+        snprintf(err, errcap, "write error closing %s: %s", w->path, strerror(errno));
+        rc = -1;
+    }
+    w->fd = -1;
+    gcn10_tiff_abort(w);
+    return rc;
+}
+
+void gcn10_tiff_abort(gcn10_tiff_writer *w)
+{
+    if (!w)
+        return;
+    if (w->fd >= 0)
+        close(w->fd);
+    free(w->offsets);
+    free(w->counts);
+    free(w->path);
+    free_georef(&w->georef);
+    pthread_mutex_destroy(&w->mu);
+    free(w);
+}
+
+size_t gcn10_deflate_tile(const uint8_t *src, size_t stride, int valid_w, int valid_h, int level,
+                          uint8_t *dst, size_t dstcap)
+{
+    unsigned char tile[TILE * TILE];
+    uLongf dl = (uLongf)dstcap;
+
+    if (valid_w <= 0 || valid_h <= 0 || valid_w > TILE || valid_h > TILE)
+        return 0;
+    if (valid_w < TILE || valid_h < TILE)
+        memset(tile, 0, sizeof tile);
+    for (int y = 0; y < valid_h; y++)
+        memcpy(tile + (size_t)y * TILE, src + (size_t)y * stride, (size_t)valid_w);
+    if (compress2(dst, &dl, tile, sizeof tile, level > 0 ? level : Z_DEFAULT_COMPRESSION) != Z_OK)
+        return 0;
+    return (size_t)dl;
+}
+
+int gcn10_save_raster(const uint8_t *data, int xsize, int ysize, const double gt[6],
+                      const gcn10_georef *georef, const char *path, int level, char *err,
+                      size_t errcap)
+{
+    gcn10_tiff_writer *w = gcn10_tiff_create(path, xsize, ysize, gt, georef, err, errcap);
+    size_t cap = compressBound(TILE * TILE);
+    uint8_t *z;
+
+    if (!w)
+        return -1;
+    z = malloc(cap);
+    if (!z) {
+        snprintf(err, errcap, "out of memory writing %s", path);
+        gcn10_tiff_abort(w);
+        return -1;
+    }
+    for (int ty = 0; ty < w->down; ty++) {
+        for (int tx = 0; tx < w->across; tx++) {
+            int vw = xsize - tx * TILE < TILE ? xsize - tx * TILE : TILE;
+            int vh = ysize - ty * TILE < TILE ? ysize - ty * TILE : TILE;
+            size_t n = gcn10_deflate_tile(data + (size_t)ty * TILE * (size_t)xsize + (size_t)tx * TILE,
+                                          (size_t)xsize, vw, vh, level, z, cap);
+
+            if (n == 0 || gcn10_tiff_put_tile(w, tx, ty, z, n) != 0) {
+                snprintf(err, errcap, "write error %d on %s", 3, path);     /* CE_Failure, src/raster.c:221 */
+                free(z);
+                gcn10_tiff_abort(w);
+                return -1;
+            }
+        }
+    }
+    free(z);
+    return gcn10_tiff_finish(w, err, errcap);
+}

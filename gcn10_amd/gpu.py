@@ -37,7 +37,7 @@ ABI_SYMBOLS = (
     "gcn10_gpu_event_sync", "gcn10_gpu_stream_wait_event", "gcn10_gpu_event_elapsed_ms",
     "gcn10_gpu_set_tables", "gcn10_gpu_resample", "gcn10_gpu_modify_hysogs_data",
     "gcn10_gpu_calculate_cn", "gcn10_gpu_prepare_tile", "gcn10_gpu_cn_strip",
-    "gcn10_gpu_strip_algorithmic_bytes", "gcn10_gpu_last_kernel_name",
+    "gcn10_gpu_strip_algorithmic_bytes", "gcn10_gpu_last_kernel_name", "gcn10_gpu_set_option",
 )
 
 
@@ -88,6 +88,7 @@ def lib():
             "gcn10_gpu_cn_strip": (i, [vp, vp, i, i, vp, u, u, C.POINTER(vp), vp]),
             "gcn10_gpu_strip_algorithmic_bytes": (sz, [i, i, i, i, u, u]),
             "gcn10_gpu_last_kernel_name": (C.c_char_p, [vp]),
+            "gcn10_gpu_set_option": (i, [vp, C.c_char_p, i]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -237,6 +238,10 @@ class Engine:
         self._chk(lib().gcn10_gpu_event_elapsed_ms(self._ctx, e0, e1, C.byref(ms)),
                   "gcn10_gpu_event_elapsed_ms")
         return float(ms.value)
+
+    def set_option(self, name: str, value: int):
+        self._chk(lib().gcn10_gpu_set_option(self._ctx, name.encode(), int(value)),
+                  "gcn10_gpu_set_option")
 
     def last_kernel_name(self) -> str:
         return lib().gcn10_gpu_last_kernel_name(self._ctx).decode()

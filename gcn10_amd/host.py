@@ -40,8 +40,155 @@ def lib():
                                           C.POINTER(C.c_int), C.POINTER(C.c_int),
                                           C.POINTER(C.c_int), _f64p]
         L.gcn10_raster_window.restype = C.c_int
+        vp, ip, cp = C.c_void_p, C.POINTER(C.c_int), C.c_char_p
+        L.gcn10_config_parse.argtypes = [cp, C.POINTER(Config), cp, C.c_size_t]
+        L.gcn10_config_parse.restype = C.c_int
+        L.gcn10_config_free.argtypes = [C.POINTER(Config)]
+        L.gcn10_config_free.restype = None
+        L.gcn10_log_open.argtypes = [cp, C.c_int]
+        L.gcn10_log_open.restype = vp
+        L.gcn10_log_message.argtypes = [vp, cp, cp, C.c_bool]
+        L.gcn10_log_message.restype = None
+        L.gcn10_log_close.argtypes = [vp]
+        L.gcn10_log_close.restype = None
+        L.gcn10_read_block_list.argtypes = [cp, ip]
+        L.gcn10_read_block_list.restype = C.POINTER(C.c_int)
+        L.gcn10_blocks_open.argtypes = [cp, C.POINTER(Blocks), cp, C.c_size_t]
+        L.gcn10_blocks_open.restype = C.c_int
+        L.gcn10_blocks_free.argtypes = [C.POINTER(Blocks)]
+        L.gcn10_blocks_free.restype = None
+        L.gcn10_blocks_find.argtypes = [C.POINTER(Blocks), C.c_int]
+        L.gcn10_blocks_find.restype = C.c_int
+        L.gcn10_raster_open.argtypes = [cp, cp, cp, C.c_size_t]
+        L.gcn10_raster_open.restype = vp
+        L.gcn10_raster_close.argtypes = [vp]
+        L.gcn10_raster_close.restype = None
+        L.gcn10_raster_info.argtypes = [vp, ip, ip, _f64p]
+        L.gcn10_raster_info.restype = None
+        L.gcn10_raster_read.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, cp, C.c_size_t]
+        L.gcn10_raster_read.restype = C.c_int
+        L.gcn10_raster_georef.argtypes = [vp]
+        L.gcn10_raster_georef.restype = vp
+        L.gcn10_save_raster.argtypes = [vp, C.c_int, C.c_int, _f64p, vp, cp, C.c_int, cp, C.c_size_t]
+        L.gcn10_save_raster.restype = C.c_int
+        L.free_ = C.CDLL(None).free
+        L.free_.argtypes = [vp]
+        L.free_.restype = None
         _lib = L
     return _lib
+
+
+class Config(C.Structure):
+    """``gcn10_config`` of include/gcn10_host.h."""
+    _fields_ = [("hysogs_data_path", C.c_char_p), ("esa_data_path", C.c_char_p),
+                ("blocks_shp_path", C.c_char_p), ("lookup_table_path", C.c_char_p),
+                ("log_dir", C.c_char_p), ("gpus", C.c_int), ("strip_rows", C.c_int),
+                ("io_threads", C.c_int), ("deflate_level", C.c_int), ("esa_tile_dir", C.c_char_p)]
+
+
+class Blocks(C.Structure):
+    _fields_ = [("n", C.c_int), ("id", C.POINTER(C.c_int)), ("bbox", C.POINTER(C.c_double * 4))]
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def parse_config(path: str) -> dict:
+    """src/config.c:44-114 -> dict of the keys; raises HostError like the reference aborts."""
+    cfg = Config()
+    err = C.create_string_buffer(1024)
+    rc = lib().gcn10_config_parse(os.fsencode(path), C.byref(cfg), err, 1024)
+    if rc != 0:
+        raise HostError(err.value.decode())
+    out = {}
+    for name, _t in Config._fields_:
+        v = getattr(cfg, name)
+        out[name] = v.decode() if isinstance(v, bytes) else v
+    lib().gcn10_config_free(C.byref(cfg))
+    return out
+
+
+class Log:
+    def __init__(self, log_dir: str, rank: int):
+        self._h = lib().gcn10_log_open(os.fsencode(log_dir), rank)
+
+    def message(self, level, msg, also_console=False):
+        lib().gcn10_log_message(self._h, None if level is None else level.encode(),
+                                None if msg is None else msg.encode(), also_console)
+
+    def close(self):
+        if self._h:
+            lib().gcn10_log_close(self._h)
+            self._h = None
+
+
+def read_block_list(path: str):
+    n = C.c_int(0)
+    p = lib().gcn10_read_block_list(os.fsencode(path), C.byref(n))
+    if not p:
+        return None
+    ids = [p[i] for i in range(n.value)]
+    lib().free_(C.cast(p, C.c_void_p))
+    return ids
+
+
+def read_blocks_shapefile(path: str):
+    """-> (ids list, bbox float64[n,4] {minx,miny,maxx,maxy})."""
+    b = Blocks()
+    err = C.create_string_buffer(1024)
+    if lib().gcn10_blocks_open(os.fsencode(path), C.byref(b), err, 1024) != 0:
+        raise HostError(err.value.decode())
+    ids = [b.id[i] for i in range(b.n)]
+    bbox = np.array([list(b.bbox[i]) for i in range(b.n)], dtype=np.float64).reshape(b.n, 4)
+    lib().gcn10_blocks_free(C.byref(b))
+    return ids, bbox
+
+
+class Raster:
+    """An open GeoTIFF / VRT (``gcn10_raster``)."""
+
+    def __init__(self, path: str, tile_dir: str | None = None):
+        err = C.create_string_buffer(1024)
+        self._h = lib().gcn10_raster_open(os.fsencode(path),
+                                          os.fsencode(tile_dir) if tile_dir else None, err, 1024)
+        if not self._h:
+            raise HostError(err.value.decode())
+        xs, ys = C.c_int(), C.c_int()
+        gt = np.empty(6, dtype=np.float64)
+        lib().gcn10_raster_info(self._h, C.byref(xs), C.byref(ys), gt)
+        self.xsize, self.ysize, self.gt = xs.value, ys.value, gt.tolist()
+
+    def read(self, xoff, yoff, xcount, ycount) -> np.ndarray:
+        out = np.empty((ycount, xcount), dtype=np.uint8)
+        err = C.create_string_buffer(1024)
+        if lib().gcn10_raster_read(self._h, xoff, yoff, xcount, ycount, out.ctypes.data, err, 1024) != 0:
+            raise HostError(err.value.decode())
+        return out
+
+    def georef_ptr(self):
+        return lib().gcn10_raster_georef(self._h)
+
+    def close(self):
+        if self._h:
+            lib().gcn10_raster_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def save_raster(data: np.ndarray, gt, path: str, georef_ptr=None, level: int = 0):
+    """src/raster.c:192-227: tiled DEFLATE GeoTIFF of a uint8 raster."""
+    a = np.ascontiguousarray(data, dtype=np.uint8)
+    err = C.create_string_buffer(1024)
+    rc = lib().gcn10_save_raster(a.ctypes.data, a.shape[1], a.shape[0], _f(gt, 6), georef_ptr,
+                                 os.fsencode(path), level, err, 1024)
+    if rc != 0:
+        raise HostError(err.value.decode())
 
 
 def _f(v, n):

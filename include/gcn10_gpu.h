@@ -167,6 +167,11 @@ int gcn10_gpu_cn_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, int rows,
 size_t gcn10_gpu_strip_algorithmic_bytes(int W, int rows, int hsx, int hsy,
                                          unsigned cond_mask, unsigned table_mask);
 
+/* Launch-shape knobs of the strip kernels, for tuning runs; results never
+ * depend on them.  Names: "grid_blocks_per_cu" (1..64), "ilp16" (1|2),
+ * "ilp1" (1|2|4), "nontemporal" (0|1), "xcd_slabs" (0|1). */
+int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value);
+
 /* Name of the variant of the strip kernel the last cn_strip call launched
  * (for profiles and bench records). */
 const char *gcn10_gpu_last_kernel_name(gcn10_gpu_ctx *ctx);

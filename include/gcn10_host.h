@@ -73,6 +73,120 @@ int gcn10_raster_window(const double t[6], int rx, int ry, const double bbox[4],
                         int *xoff, int *yoff, int *xcount, int *ycount,
                         double gt[6]);
 
+
+/* ------------------------------------------------------------------------ */
+/* config (src/config.c) and logging (src/log.c)                            */
+/* ------------------------------------------------------------------------ */
+
+/* The five required keys of the reference's config file (src/config.c:69-103,
+ * 107-113) plus optional keys this program adds; unknown keys and lines
+ * without '=' are ignored, '#' starts a comment line, lines are cut at 511
+ * bytes (src/config.c:47-64). */
+typedef struct gcn10_config {
+    char *hysogs_data_path;
+    char *esa_data_path;
+    char *blocks_shp_path;
+    char *lookup_table_path;
+    char *log_dir;
+    /* optional extensions (absent = default) */
+    int gpus;               /* "gpus": number of GPUs to use, 0 = all visible      */
+    int strip_rows;         /* "strip_rows": rows per staging strip, 0 = default   */
+    int io_threads;         /* "io_threads": tile compression threads, 0 = auto    */
+    int deflate_level;      /* "deflate_level": zlib level 1..9, 0 = zlib default 6 */
+    char *esa_tile_dir;     /* "esa_tile_dir": local mirror of /vsicurl/ VRT sources */
+} gcn10_config;
+
+/* Returns 0; -1 cannot open (message in err); -2 a required key is missing
+ * (the reference aborts in both cases, src/config.c:50-54, 107-113). */
+int gcn10_config_parse(const char *path, gcn10_config *cfg, char *err, size_t errcap);
+void gcn10_config_free(gcn10_config *cfg);
+
+/* Per-worker log, "<log_dir>/rank_<r>.log", append mode, lines
+ * "[%Y-%m-%dT%H:%M:%S] [LEVEL] [rank r] msg" (src/log.c:67-86, 149-166).
+ * A "rank" is a GPU worker here.  Thread safe. */
+typedef struct gcn10_log gcn10_log;
+gcn10_log *gcn10_log_open(const char *log_dir, int rank);       /* = init_logging  */
+void gcn10_log_message(gcn10_log *lg, const char *level, const char *msg,
+                       bool also_console);                      /* = log_message   */
+void gcn10_log_close(gcn10_log *lg);                            /* = finalize_logging */
+
+/* ------------------------------------------------------------------------ */
+/* block index (src/raster.c:23-103, src/cn.c:155-184)                      */
+/* ------------------------------------------------------------------------ */
+
+/* Whitespace-separated integers; parsing stops at the first token that is not
+ * an integer (fscanf("%d"), src/raster.c:46).  Returns a malloc'd array. */
+int *gcn10_read_block_list(const char *path, int *n_blocks);
+
+/* The polygon shapefile of block extents, read without OGR: the .shp record
+ * bounding boxes and the "ID" column of the .dbf. */
+typedef struct gcn10_blocks {
+    int n;
+    int *id;                /* "ID" attribute of every feature, file order   */
+    double (*bbox)[4];      /* {minx, miny, maxx, maxy} = OGR envelope       */
+} gcn10_blocks;
+
+int gcn10_blocks_open(const char *shp_path, gcn10_blocks *out, char *err, size_t errcap);
+void gcn10_blocks_free(gcn10_blocks *b);
+/* First feature whose ID equals block_id (the reference's attribute filter +
+ * first feature, src/cn.c:162-171); returns its index or -1. */
+int gcn10_blocks_find(const gcn10_blocks *b, int block_id);
+
+/* ------------------------------------------------------------------------ */
+/* rasters (src/raster.c:106-227) without GDAL                               */
+/* ------------------------------------------------------------------------ */
+
+typedef struct gcn10_raster gcn10_raster;   /* an open GeoTIFF or VRT, 1 band, Byte */
+
+/* GeoTIFF (classic or BigTIFF; strips or tiles; none / LZW / DEFLATE /
+ * PackBits; predictor 1 or 2) or a VRT mosaic of such files. */
+gcn10_raster *gcn10_raster_open(const char *path, const char *vrt_tile_dir,
+                                char *err, size_t errcap);
+void gcn10_raster_close(gcn10_raster *r);
+void gcn10_raster_info(const gcn10_raster *r, int *xsize, int *ysize, double gt[6]);
+/* Rows [yoff, yoff+ycount) x columns [xoff, xoff+xcount) into dst (row-major,
+ * xcount bytes per row).  Thread safe per raster handle.  0 or -1. */
+int gcn10_raster_read(gcn10_raster *r, int xoff, int yoff, int xcount, int ycount,
+                      uint8_t *dst, char *err, size_t errcap);
+
+/* Georeferencing tags an output inherits from the landcover input (the
+ * reference copies the input's WKT, src/raster.c:212-214). */
+typedef struct gcn10_georef {
+    uint16_t *geokeys;      /* GeoKeyDirectoryTag (34735) */
+    int n_geokeys;
+    double *geodoubles;     /* GeoDoubleParamsTag (34736) */
+    int n_geodoubles;
+    char *geoascii;         /* GeoAsciiParamsTag (34737), NUL terminated */
+} gcn10_georef;
+const gcn10_georef *gcn10_raster_georef(const gcn10_raster *r);
+
+/* Streaming writer of one tiled DEFLATE GeoTIFF (GTiff, COMPRESS=DEFLATE,
+ * TILED=YES -> 256x256 tiles, Byte, 1 band; src/raster.c:204-209).  Tiles may
+ * be handed over already compressed (zlib streams), in any order. */
+typedef struct gcn10_tiff_writer gcn10_tiff_writer;
+gcn10_tiff_writer *gcn10_tiff_create(const char *path, int xsize, int ysize,
+                                     const double gt[6], const gcn10_georef *georef,
+                                     char *err, size_t errcap);
+int gcn10_tiff_tiles_across(const gcn10_tiff_writer *w);
+int gcn10_tiff_tiles_down(const gcn10_tiff_writer *w);
+/* Appends one compressed tile (tx, ty) of `nbytes` zlib-stream bytes. */
+int gcn10_tiff_put_tile(gcn10_tiff_writer *w, int tx, int ty, const void *zdata, size_t nbytes);
+/* Writes the directory and closes the file.  0 or -1. */
+int gcn10_tiff_finish(gcn10_tiff_writer *w, char *err, size_t errcap);
+void gcn10_tiff_abort(gcn10_tiff_writer *w);
+
+/* zlib-compresses one 256x256 tile cut from a raster strip (rows are `stride`
+ * bytes apart; the part of the tile outside the raster is zero-filled as GDAL
+ * pads edge tiles).  Returns the compressed size or 0 on error. */
+size_t gcn10_deflate_tile(const uint8_t *src, size_t stride, int valid_w, int valid_h,
+                          int level, uint8_t *dst, size_t dstcap);
+
+/* Convenience: whole raster in memory -> file (the reference's save_raster
+ * signature, src/raster.c:192-194).  0 or -1. */
+int gcn10_save_raster(const uint8_t *data, int xsize, int ysize, const double gt[6],
+                      const gcn10_georef *georef, const char *path, int level,
+                      char *err, size_t errcap);
+
 #ifdef __cplusplus
 }
 #endif

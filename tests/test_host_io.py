@@ -1,0 +1,289 @@
+"""Host I/O of the gcn10 program: config, logs, block index, GeoTIFF/VRT read, GeoTIFF write.
+Independent checkers: Pillow (libtiff) for TIFF bytes, a Python TIFF/LZW producer for inputs."""
+import os
+import re
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from gcn10_amd import host
+from oracle import cn_oracle_c as oc
+from tests import tiffutil
+from tests.conftest import GOLDEN
+
+Image.MAX_IMAGE_PIXELS = None
+
+
+# ---- config (src/config.c) ------------------------------------------------
+
+def test_config_reference_file_shape(tmp_path):
+    p = tmp_path / "config.txt"
+    p.write_text("# comment\n\nhysogs_data_path=../../hsg/HYSOGs250m_4326_lzw.tif\n"
+                 "  esa_data_path =  ../../landcover/esa_worldcover_2021.vrt  \n"
+                 "blocks_shp_path=../../blocks/esa_extent_blocks.shp\nlookup_table_path=../../lookups\n"
+                 "log_dir=logs/\nunknown_key=1\nno equals sign here\nlog_dir=logs2/\n")
+    c = host.parse_config(str(p))
+    assert c["hysogs_data_path"] == "../../hsg/HYSOGs250m_4326_lzw.tif"
+    assert c["esa_data_path"] == "../../landcover/esa_worldcover_2021.vrt"     # trimmed
+    assert c["log_dir"] == "logs2/"                                            # last one wins
+    assert c["gpus"] == 0 and c["esa_tile_dir"] is None
+
+
+def test_config_optional_keys_and_errors(tmp_path):
+    p = tmp_path / "c.txt"
+    base = "hysogs_data_path=a\nesa_data_path=b\nblocks_shp_path=c\nlookup_table_path=d\nlog_dir=e\n"
+    p.write_text(base + "gpus=4\nstrip_rows=512\nio_threads=3\ndeflate_level=1\nesa_tile_dir=/x\n")
+    c = host.parse_config(str(p))
+    assert (c["gpus"], c["strip_rows"], c["io_threads"], c["deflate_level"], c["esa_tile_dir"]) == \
+        (4, 512, 3, 1, "/x")
+    p.write_text("hysogs_data_path=a\nesa_data_path=b\n")
+    with pytest.raises(host.HostError, match="missing one of: hysogs_data_path"):      # src/config.c:109
+        host.parse_config(str(p))
+    with pytest.raises(host.HostError, match="cannot open config"):                    # src/config.c:52
+        host.parse_config(str(tmp_path / "nope.txt"))
+
+
+# ---- logging (src/log.c) ----------------------------------------------------
+
+def test_log_format(tmp_path):
+    d = tmp_path / "logs"
+    lg = host.Log(str(d), 3)
+    lg.message("INFO", "processing block 2234")
+    lg.message("ERROR", "block 7 not found", also_console=True)
+    lg.message(None, None)
+    lg.close()
+    lines = (d / "rank_3.log").read_text().splitlines()
+    ts = r"\[\d{4}-\d\d-\d\dT\d\d:\d\d:\d\d\]"
+    assert re.fullmatch(ts + r" \[rank 3\] logging started", lines[0])                 # src/log.c:112
+    assert re.fullmatch(ts + r" \[INFO\] \[rank 3\] processing block 2234", lines[1])  # src/log.c:159
+    assert re.fullmatch(ts + r" \[ERROR\] \[rank 3\] block 7 not found", lines[2])
+    assert re.fullmatch(ts + r" \[INFO\] \[rank 3\] ", lines[3])
+    assert re.fullmatch(ts + r" \[rank 3\] logging finished", lines[4])                # src/log.c:264
+    lg = host.Log(str(d), 3)        # append mode (src/log.c:76)
+    lg.close()
+    assert len((d / "rank_3.log").read_text().splitlines()) == 7
+
+
+# ---- block index ------------------------------------------------------------
+
+def test_block_list_parsing(tmp_path):
+    p = tmp_path / "blocks.txt"
+    p.write_text("2234\n2261 2256\t2257\n\n 2290 x 99\n")
+    assert host.read_block_list(str(p)) == [2234, 2261, 2256, 2257, 2290]    # stops at 'x' (src/raster.c:46)
+    p.write_text("")
+    assert host.read_block_list(str(p)) == []
+    assert host.read_block_list(str(tmp_path / "missing.txt")) is None
+    p.write_text(" ".join(str(i) for i in range(1000)))
+    assert host.read_block_list(str(p)) == list(range(1000))
+
+
+def test_reference_block_shapefile():
+    ids, bbox = host.read_blocks_shapefile(os.path.join(GOLDEN, "blocks", "esa_extent_blocks.shp"))
+    assert len(ids) == 2651 and min(ids) == 3 and max(ids) == 2653 and len(set(ids)) == 2651
+    assert np.all(bbox[:, 2] - bbox[:, 0] == 3.0) and np.all(bbox[:, 3] - bbox[:, 1] == 3.0)
+    assert np.all(bbox == np.round(bbox))                      # integer degrees
+    i = ids.index(2234)                                        # first id of src/test/blocks.txt
+    assert bbox[i].tolist() == [-114.0, 39.0, -111.0, 42.0]
+    # every block gives the 36001 / 36000 windows of SURVEY.md section 7 on the real VRT grid
+    vrt_gt = [-180.0, 8.3333333333330430e-05, 0.0, 84.0, 0.0, -8.3333333333330430e-05]
+    sizes = set()
+    for b in bbox[::50]:
+        w = host.raster_window(vrt_gt, 4320000, 1728000, b.tolist())
+        assert w == oc.window(vrt_gt, 4320000, 1728000, b.tolist())
+        sizes.add((w[2], w[3]))
+    assert sizes <= {(36001, 36001), (36000, 36001), (36001, 36000), (36000, 36000)}
+
+
+@pytest.mark.parametrize("shape_type", [5, 15])
+def test_synthetic_block_shapefile(tmp_path, shape_type):
+    blocks = [(7, -3.0, 0.0, 0.0, 3.0), (12, 0.0, 0.0, 3.0, 3.0), (1000, 10.5, -20.25, 11.0, -19.0), (7, 1, 1, 2, 2)]
+    base = str(tmp_path / "b")
+    tiffutil.write_block_shapefile(base, blocks, shape_type)
+    ids, bbox = host.read_blocks_shapefile(base + ".shp")
+    assert ids == [7, 12, 1000, 7]
+    assert np.array_equal(bbox, np.array([b[1:] for b in blocks], dtype=np.float64))
+    with pytest.raises(host.HostError, match="ogr open failed"):           # src/cn.c:157
+        host.read_blocks_shapefile(str(tmp_path / "none.shp"))
+
+
+# ---- GeoTIFF reader ---------------------------------------------------------
+
+def _img(seed, H, W):
+    rng = np.random.default_rng(seed)
+    small = rng.integers(0, 12, size=((H + 7) // 8, (W + 7) // 8), dtype=np.uint8) * 10
+    img = np.repeat(np.repeat(small, 8, axis=0), 8, axis=1)[:H, :W].copy()
+    noise = rng.integers(0, 256, size=(H, W), dtype=np.uint8)
+    return np.where(noise < 40, noise, img).astype(np.uint8)
+
+
+GT = [-111.0, 0.01, 0.0, 39.0, 0.0, -0.02]
+
+VARIANTS = [
+    dict(compression=1), dict(compression=1, rows_per_strip=7), dict(compression=8, rows_per_strip=16),
+    dict(compression=32946), dict(compression=5), dict(compression=5, rows_per_strip=5),
+    dict(compression=5, predictor=2), dict(compression=8, predictor=2, rows_per_strip=3),
+    dict(compression=32773, rows_per_strip=9), dict(compression=1, tile=(16, 16)),
+    dict(compression=8, tile=(32, 16)), dict(compression=5, tile=(64, 64)),
+    dict(compression=5, tile=(16, 32), predictor=2), dict(compression=8, big_endian=True),
+    dict(compression=5, bigtiff=True, tile=(32, 32)), dict(compression=1, bigtiff=True, big_endian=True),
+]
+
+
+@pytest.mark.parametrize("kw", VARIANTS, ids=[str(sorted(v.items())) for v in VARIANTS])
+def test_tiff_reader_variants(tmp_path, kw):
+    img = _img(len(str(kw)), 75, 101)
+    p = str(tmp_path / "t.tif")
+    tiffutil.write_tiff(p, img, gt=GT, **kw)
+    if not kw.get("bigtiff"):
+        # the producer itself is checked by libtiff (through Pillow)
+        assert np.array_equal(np.array(Image.open(p)), img)
+    with host.Raster(p) as r:
+        assert (r.xsize, r.ysize) == (101, 75)
+        assert r.gt == GT
+        assert np.array_equal(r.read(0, 0, 101, 75), img)
+        assert np.array_equal(r.read(13, 9, 50, 41), img[9:50, 13:63])
+        assert np.array_equal(r.read(100, 74, 1, 1), img[74:, 100:])
+        with pytest.raises(host.HostError):
+            r.read(90, 0, 20, 5)
+
+
+def test_tiff_reader_pillow_written_files(tmp_path):
+    img = _img(5, 300, 257)
+    for comp in ("raw", "tiff_lzw", "tiff_adobe_deflate", "packbits"):
+        p = str(tmp_path / ("p_%s.tif" % comp))
+        Image.fromarray(img).save(p, compression=None if comp == "raw" else comp)
+        with host.Raster(p) as r:
+            assert np.array_equal(r.read(0, 0, 257, 300), img), comp
+
+
+def test_tiff_reader_pixel_is_point_and_errors(tmp_path):
+    img = _img(1, 10, 10)
+    p = str(tmp_path / "pt.tif")
+    tiffutil.write_tiff(p, img, gt=GT, pixel_is_point=True)
+    with host.Raster(p) as r:       # GDAL shifts the origin by half a pixel for PixelIsPoint
+        assert r.gt[0] == GT[0] - 0.5 * GT[1] and r.gt[3] == GT[3] - 0.5 * GT[5]
+    (tmp_path / "junk.tif").write_bytes(b"not a tiff at all")
+    with pytest.raises(host.HostError, match="gdal open failed"):          # src/raster.c:121
+        host.Raster(str(tmp_path / "junk.tif"))
+    with pytest.raises(host.HostError, match="gdal open failed"):
+        host.Raster(str(tmp_path / "missing.tif"))
+    Image.fromarray(img.astype(np.uint16) * 100).save(str(tmp_path / "u16.tif"))
+    with pytest.raises(host.HostError, match="only Byte rasters"):
+        host.Raster(str(tmp_path / "u16.tif"))
+
+
+def test_lzw_long_runs_and_table_resets(tmp_path):
+    # > 4094 dictionary entries forces ClearCodes; long runs hit the KwKwK case
+    rng = np.random.default_rng(3)
+    img = np.concatenate([np.zeros((40, 512), np.uint8), rng.integers(0, 256, (200, 512), dtype=np.uint8),
+                          np.full((40, 512), 200, np.uint8)])
+    p = str(tmp_path / "lzw.tif")
+    tiffutil.write_tiff(p, img, compression=5)
+    assert np.array_equal(np.array(Image.open(p)), img)
+    with host.Raster(p) as r:
+        assert np.array_equal(r.read(0, 0, 512, 280), img)
+
+
+# ---- VRT ------------------------------------------------------------------------
+
+def _make_vrt(tmp_path, vsicurl=False):
+    a, b = _img(11, 64, 64), _img(12, 64, 64)
+    a[a == 0] = 10
+    b[:8, :8] = 0                       # NODATA region of the second source
+    tiffutil.write_tiff(str(tmp_path / "tile_a.tif"), a, compression=8, tile=(32, 32))
+    tiffutil.write_tiff(str(tmp_path / "tile_b.tif"), b, compression=5)
+    pre = "/vsicurl/https://example.invalid/v200/" if vsicurl else ""
+    rel = "0" if vsicurl else "1"
+    vrt = """<VRTDataset rasterXSize="160" rasterYSize="96">
+  <GeoTransform> -1.8000000000000000e+02,  8.3333333333330430e-05,  0.0000000000000000e+00,  8.4000000000000000e+01,  0.0000000000000000e+00, -8.3333333333330430e-05</GeoTransform>
+  <VRTRasterBand dataType="Byte" band="1">
+    <NoDataValue>0</NoDataValue>
+    <ComplexSource resampling="nearest">
+      <SourceFilename relativeToVRT="%s">%stile_a.tif</SourceFilename>
+      <SourceBand>1</SourceBand>
+      <SrcRect xOff="0" yOff="0" xSize="64" ySize="64" />
+      <DstRect xOff="16" yOff="8" xSize="64" ySize="64" />
+      <NODATA>0</NODATA>
+    </ComplexSource>
+    <ComplexSource resampling="nearest">
+      <SourceFilename relativeToVRT="%s">%stile_b.tif</SourceFilename>
+      <SourceBand>1</SourceBand>
+      <SrcRect xOff="0" yOff="0" xSize="64" ySize="64" />
+      <DstRect xOff="72" yOff="20" xSize="64" ySize="64" />
+      <NODATA>0</NODATA>
+    </ComplexSource>
+  </VRTRasterBand>
+</VRTDataset>
+""" % (rel, pre, rel, pre)
+    (tmp_path / "m.vrt").write_text(vrt)
+    exp = np.zeros((96, 160), np.uint8)
+    exp[8:72, 16:80] = a
+    sub = exp[20:84, 72:136]
+    exp[20:84, 72:136] = np.where(b != 0, b, sub)
+    return exp
+
+
+def test_vrt_mosaic(tmp_path):
+    exp = _make_vrt(tmp_path)
+    with host.Raster(str(tmp_path / "m.vrt")) as r:
+        assert (r.xsize, r.ysize) == (160, 96)
+        assert r.gt == [-180.0, 8.3333333333330430e-05, 0.0, 84.0, 0.0, -8.3333333333330430e-05]
+        assert np.array_equal(r.read(0, 0, 160, 96), exp)
+        assert np.array_equal(r.read(60, 10, 50, 40), exp[10:50, 60:110])
+        assert not r.read(140, 0, 20, 8).any()          # nothing there: NoData 0
+
+
+def test_vrt_vsicurl_sources_need_a_local_mirror(tmp_path):
+    exp = _make_vrt(tmp_path, vsicurl=True)
+    with host.Raster(str(tmp_path / "m.vrt"), tile_dir=str(tmp_path)) as r:
+        assert np.array_equal(r.read(0, 0, 160, 96), exp)
+    with host.Raster(str(tmp_path / "m.vrt")) as r:     # no mirror: the read fails, loudly
+        with pytest.raises(host.HostError, match="gdal open failed"):
+            r.read(0, 0, 160, 96)
+        assert not r.read(140, 0, 20, 8).any()          # windows that touch no source still work
+
+
+def test_reference_vrt_header_parses():
+    ref = "/root/reference/landcover/esa_worldcover_2021.vrt"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present (GPU box)")
+    with host.Raster(ref) as r:
+        assert (r.xsize, r.ysize) == (4320000, 1728000)
+        assert r.gt == [-180.0, 8.3333333333330430e-05, 0.0, 84.0, 0.0, -8.3333333333330430e-05]
+
+
+# ---- GeoTIFF writer (src/raster.c:192-227) -----------------------------------------
+
+@pytest.mark.parametrize("shape", [(1, 1), (256, 256), (257, 255), (300, 700), (513, 1025)])
+def test_save_raster_roundtrip(tmp_path, shape):
+    H, W = shape
+    img = _img(H + W, H, W)
+    p = str(tmp_path / "out.tif")
+    host.save_raster(img, GT, p)
+    im = Image.open(p)
+    assert np.array_equal(np.array(im), img)                        # libtiff decodes our file
+    tags = im.tag_v2
+    assert tags[259] == 8 and tags[322] == 256 and tags[323] == 256     # DEFLATE, 256x256 tiles
+    assert tags[258] == (8,) and tags[277] == 1 and tags[339] in (1, (1,))
+    assert tuple(tags[33550]) == (GT[1], -GT[5], 0.0)
+    assert tuple(tags[33922]) == (0.0, 0.0, 0.0, GT[0], GT[3], 0.0)
+    assert 4326 in tags[34735]
+    assert 42113 not in tags                                        # no NoData tag, like the reference
+    with host.Raster(p) as r:
+        assert r.gt == GT and (r.xsize, r.ysize) == (W, H)
+        assert np.array_equal(r.read(0, 0, W, H), img)
+
+
+def test_save_raster_copies_input_georef(tmp_path):
+    img = _img(2, 40, 40)
+    keys = [1, 1, 0, 4, 1024, 0, 1, 2, 1025, 0, 1, 1, 2048, 0, 1, 4326, 2054, 0, 1, 9102]
+    tiffutil.write_tiff(str(tmp_path / "in.tif"), img, gt=GT, geokeys=keys)
+    with host.Raster(str(tmp_path / "in.tif")) as r:
+        host.save_raster(img, r.gt, str(tmp_path / "out.tif"), georef_ptr=r.georef_ptr())
+    assert tuple(Image.open(str(tmp_path / "out.tif")).tag_v2[34735]) == tuple(keys)
+
+
+def test_save_raster_errors(tmp_path):
+    with pytest.raises(host.HostError, match="write error"):
+        host.save_raster(_img(1, 4, 4), GT, str(tmp_path / "no_such_dir" / "x.tif"))
