@@ -2,6 +2,7 @@
 #ifndef GCN10_HOST_INTERNAL_H
 #define GCN10_HOST_INTERNAL_H
 
+#include "gcn10_gpu.h"
 #include "gcn10_host.h"
 
 struct gcn10_tiff;      /* tiff.c: one open TIFF file */
@@ -11,5 +12,47 @@ void gcn10_tiff_reader_info(const struct gcn10_tiff *t, int *xsize, int *ysize, 
 const gcn10_georef *gcn10_tiff_reader_georef(const struct gcn10_tiff *t);
 int gcn10_tiff_read_window(struct gcn10_tiff *t, int xoff, int yoff, int xcount, int ycount,
                            uint8_t *dst, size_t dst_stride, char *err, size_t errcap);
+
+
+/* gpuapi.c: include/gcn10_gpu.h bound with dlopen */
+struct gcn10_gpu_api {
+    bool loaded;
+    int (*abi_version)(void);
+    int (*device_count)(void);
+    int (*init)(int, gcn10_gpu_ctx **);
+    void (*destroy)(gcn10_gpu_ctx *);
+    const char *(*last_error)(void);
+    int (*device_info)(gcn10_gpu_ctx *, char *, size_t, size_t *);
+    int (*malloc)(gcn10_gpu_ctx *, size_t, void **);
+    int (*free)(gcn10_gpu_ctx *, void *);
+    int (*host_alloc)(gcn10_gpu_ctx *, size_t, void **);
+    int (*host_free)(gcn10_gpu_ctx *, void *);
+    int (*memcpy_h2d)(gcn10_gpu_ctx *, void *, const void *, size_t, gcn10_stream_t);
+    int (*memcpy_d2h)(gcn10_gpu_ctx *, void *, const void *, size_t, gcn10_stream_t);
+    int (*memset)(gcn10_gpu_ctx *, void *, int, size_t, gcn10_stream_t);
+    int (*stream_create)(gcn10_gpu_ctx *, gcn10_stream_t *);
+    int (*stream_destroy)(gcn10_gpu_ctx *, gcn10_stream_t);
+    int (*stream_sync)(gcn10_gpu_ctx *, gcn10_stream_t);
+    int (*device_sync)(gcn10_gpu_ctx *);
+    int (*event_create)(gcn10_gpu_ctx *, gcn10_event_t *);
+    int (*event_destroy)(gcn10_gpu_ctx *, gcn10_event_t);
+    int (*event_record)(gcn10_gpu_ctx *, gcn10_event_t, gcn10_stream_t);
+    int (*event_sync)(gcn10_gpu_ctx *, gcn10_event_t);
+    int (*stream_wait_event)(gcn10_gpu_ctx *, gcn10_stream_t, gcn10_event_t);
+    int (*event_elapsed_ms)(gcn10_gpu_ctx *, gcn10_event_t, gcn10_event_t, float *);
+    int (*set_tables)(gcn10_gpu_ctx *, const int *, int);
+    int (*prepare_tile)(gcn10_gpu_ctx *, const uint8_t *, int, int, const int32_t *, int,
+                        gcn10_stream_t);
+    int (*cn_strip)(gcn10_gpu_ctx *, const uint8_t *, int, int, const int32_t *, unsigned, unsigned,
+                    uint8_t *const[GCN10_N_RASTERS], gcn10_stream_t);
+};
+const struct gcn10_gpu_api *gcn10_gpu_api_get(char *err, size_t errcap);
+
+/* pool.c: fixed thread pool for tile compression */
+typedef struct gcn10_pool gcn10_pool;
+typedef void (*gcn10_job_fn)(void *arg);
+gcn10_pool *gcn10_pool_create(int n_threads);
+void gcn10_pool_submit(gcn10_pool *p, gcn10_job_fn fn, void *arg);
+void gcn10_pool_destroy(gcn10_pool *p);     /* drains the queue first */
 
 #endif

@@ -1,0 +1,798 @@
+/* pipeline.c -- the run: block queue over GPUs and the per-block pipeline.
+ *
+ * What the reference does per block on one MPI rank
+ * (/root/reference/src/cn.c:134-384): find the block's bbox, load the
+ * landcover window and the soil window with GDAL, upsample, then 18 times
+ * {read CSV, memcpy, remap, memset, lookup, GDAL DEFLATE write}.
+ *
+ * Here, per block on one GPU worker thread:
+ *   host   bbox -> windows (geo.c, bit-exact) -> soil window + index maps -> HBM
+ *   strips landcover rows are decoded straight into a pinned strip buffer,
+ *          copied to HBM on the h2d stream, turned into 18 CN strips by ONE
+ *          fused kernel on the compute stream, copied back on the d2h stream
+ *          into pinned strip buffers; two buffer sets rotate, so file decode,
+ *          H2D, kernel, D2H and tile compression of neighbouring strips overlap
+ *   sink   every 256x256 tile of every raster of a finished strip is a job for
+ *          the compression pool, which appends it to the raster's GeoTIFF
+ * Blocks are pulled from one atomic counter by all workers (the reference's
+ * static `i += size` round-robin, src/main.c:171, made dynamic); no data moves
+ * between GPUs, so there is no collective and no RCCL.
+ */
+#include "gcn10_host.h"
+#include "host_internal.h"
+
+#include <errno.h>
+#include <limits.h>
+#include <pthread.h>
+#include <stdarg.h>
+#include <stdatomic.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+#include <zlib.h>
+
+enum { TILE = 256, NBUF = 2, DEFAULT_STRIP_ROWS = 1024 };
+
+struct run;
+
+/* one rotating set of strip buffers */
+struct strip_buf {
+    uint8_t *h_esa;                         /* pinned */
+    uint8_t *d_esa;
+    uint8_t *h_out[GCN10_N_RASTERS];        /* pinned */
+    uint8_t *d_out[GCN10_N_RASTERS];
+    gcn10_event_t ev_h2d, ev_kernel, ev_d2h;
+    /* compression jobs of the strip currently held by this buffer */
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    int pending;
+    bool d2h_issued;
+    int y0, rows;                           /* strip held */
+};
+
+struct worker {
+    struct run *run;
+    int rank;                               /* GPU index = "rank" in the logs */
+    pthread_t thread;
+    gcn10_log *log;
+    gcn10_gpu_ctx *ctx;
+    gcn10_stream_t s_h2d, s_kernel, s_d2h;
+    gcn10_raster *esa, *soil;
+    size_t buf_px;                          /* capacity of one strip buffer, pixels */
+    struct strip_buf buf[NBUF];
+    uint8_t *d_coarse;
+    size_t coarse_cap;
+    int32_t *d_ci, *d_cj;
+    size_t ci_cap, cj_cap;
+    atomic_bool failed;                     /* a sink job of the current block failed */
+    int blocks_done;
+    double busy_seconds;
+};
+
+struct run {
+    gcn10_config cfg;
+    gcn10_run_options opt;
+    const struct gcn10_gpu_api *gpu;
+    gcn10_blocks blocks;
+    int *block_ids;
+    int n_blocks;
+    int tables[9][256][5];
+    int n_workers;
+    struct worker *workers;
+    gcn10_pool *pool;
+    atomic_int next_block;
+    atomic_int fatal;                       /* a worker hit an MPI_Abort-class error */
+    int strip_rows;
+    int deflate_level;
+    bool null_sink;                         /* GCN10_SINK=null: no compression, no files */
+};
+
+static double now_seconds(void)
+{
+    struct timespec ts;
+
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void wlog(struct worker *w, const char *level, bool console, const char *fmt, ...)
+    __attribute__((format(printf, 4, 5)));
+
+static void wlog(struct worker *w, const char *level, bool console, const char *fmt, ...)
+{
+    char msg[8192];                         /* char msg[8192], src/cn.c:144 */
+    va_list ap;
+
+    va_start(ap, fmt);
+    vsnprintf(msg, sizeof msg, fmt, ap);
+    va_end(ap);
+    gcn10_log_message(w->log, level, msg, console);
+}
+
+/* ------------------------------------------------------------------------ */
+/* sink: tile compression jobs                                               */
+/* ------------------------------------------------------------------------ */
+
+struct tile_job {
+    struct worker *w;
+    struct strip_buf *b;
+    gcn10_tiff_writer *tif;
+    const uint8_t *strip;                   /* pinned strip of one raster */
+    int W, H;                               /* raster size */
+    int y0;                                 /* first raster row of the strip */
+    int ty;                                 /* tile row (global) */
+};
+
+static void tile_row_job(void *arg)
+{
+    struct tile_job *j = arg;
+    struct run *r = j->w->run;
+    uint8_t z[TILE * TILE + TILE * TILE / 1000 + 64];       /* >= compressBound(65536) */
+    int across = gcn10_tiff_tiles_across(j->tif);
+    int row0 = j->ty * TILE;
+    int vh = j->H - row0 < TILE ? j->H - row0 : TILE;
+
+    for (int tx = 0; tx < across; tx++) {
+        int vw = j->W - tx * TILE < TILE ? j->W - tx * TILE : TILE;
+        const uint8_t *src = j->strip + (size_t)(row0 - j->y0) * (size_t)j->W + (size_t)tx * TILE;
+        size_t n = gcn10_deflate_tile(src, (size_t)j->W, vw, vh, r->deflate_level, z, sizeof z);
+
+        if (n == 0 || gcn10_tiff_put_tile(j->tif, tx, j->ty, z, n) != 0) {
+            atomic_store(&j->w->failed, true);
+            break;
+        }
+    }
+    pthread_mutex_lock(&j->b->mu);
+    if (--j->b->pending == 0)
+        pthread_cond_broadcast(&j->b->cv);
+    pthread_mutex_unlock(&j->b->mu);
+    free(j);
+}
+
+static void wait_sink(struct strip_buf *b)
+{
+    pthread_mutex_lock(&b->mu);
+    while (b->pending > 0)
+        pthread_cond_wait(&b->cv, &b->mu);
+    pthread_mutex_unlock(&b->mu);
+}
+
+/* hands the finished strip in buffer b to the compression pool */
+static int drain_strip(struct worker *w, struct strip_buf *b, gcn10_tiff_writer *tifs[GCN10_N_RASTERS],
+                       int W, int H)
+{
+    struct run *r = w->run;
+
+    if (!b->d2h_issued)
+        return 0;
+    b->d2h_issued = false;
+    if (r->gpu->event_sync(w->ctx, b->ev_d2h) != 0) {
+        wlog(w, "ERROR", true, "gpu: %s", r->gpu->last_error());
+        return -1;
+    }
+    if (r->null_sink)
+        return 0;
+    for (int ty = b->y0 / TILE; ty * TILE < b->y0 + b->rows; ty++) {
+        for (int k = 0; k < GCN10_N_RASTERS; k++) {
+            struct tile_job *j = malloc(sizeof *j);
+
+            if (!j) {
+                wlog(w, "ERROR", true, "malloc failed for tile job");
+                return -1;
+            }
+            *j = (struct tile_job){ w, b, tifs[k], b->h_out[k], W, H, b->y0, ty };
+            pthread_mutex_lock(&b->mu);
+            b->pending++;
+            pthread_mutex_unlock(&b->mu);
+            gcn10_pool_submit(r->pool, tile_row_job, j);
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* worker resources                                                          */
+/* ------------------------------------------------------------------------ */
+
+#define GPU_TRY(w, call)                                                       \
+    do {                                                                       \
+        if ((call) != 0) {                                                     \
+            wlog((w), "ERROR", true, "gpu: %s", (w)->run->gpu->last_error());  \
+            return -1;                                                         \
+        }                                                                      \
+    } while (0)
+
+static void free_strip_buffers(struct worker *w)
+{
+    const struct gcn10_gpu_api *g = w->run->gpu;
+
+    for (int i = 0; i < NBUF; i++) {
+        struct strip_buf *b = &w->buf[i];
+
+        if (b->h_esa) g->host_free(w->ctx, b->h_esa);
+        if (b->d_esa) g->free(w->ctx, b->d_esa);
+        for (int k = 0; k < GCN10_N_RASTERS; k++) {
+            if (b->h_out[k]) g->host_free(w->ctx, b->h_out[k]);
+            if (b->d_out[k]) g->free(w->ctx, b->d_out[k]);
+            b->h_out[k] = b->d_out[k] = NULL;
+        }
+        b->h_esa = b->d_esa = NULL;
+    }
+    w->buf_px = 0;
+}
+
+/* strip buffers sized for blocks W wide: 2 x (1 + 18) pinned + the same in HBM */
+static int ensure_strip_buffers(struct worker *w, int W)
+{
+    const struct gcn10_gpu_api *g = w->run->gpu;
+    size_t px = (size_t)W * (size_t)w->run->strip_rows;
+
+    if (px <= w->buf_px)
+        return 0;
+    free_strip_buffers(w);
+    for (int i = 0; i < NBUF; i++) {
+        struct strip_buf *b = &w->buf[i];
+
+        GPU_TRY(w, g->host_alloc(w->ctx, px, (void **)&b->h_esa));
+        GPU_TRY(w, g->malloc(w->ctx, px, (void **)&b->d_esa));
+        for (int k = 0; k < GCN10_N_RASTERS; k++) {
+            GPU_TRY(w, g->host_alloc(w->ctx, px, (void **)&b->h_out[k]));
+            GPU_TRY(w, g->malloc(w->ctx, px, (void **)&b->d_out[k]));
+        }
+    }
+    w->buf_px = px;
+    return 0;
+}
+
+static int ensure_dev(struct worker *w, void **p, size_t *cap, size_t need)
+{
+    const struct gcn10_gpu_api *g = w->run->gpu;
+
+    if (need <= *cap)
+        return 0;
+    if (*p)
+        GPU_TRY(w, g->free(w->ctx, *p));
+    *p = NULL;
+    *cap = 0;
+    GPU_TRY(w, g->malloc(w->ctx, need, p));
+    *cap = need;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* one block: src/cn.c:134-384                                               */
+/* ------------------------------------------------------------------------ */
+
+/* output path with the reference's non-overwrite rule: an existing file is left
+ * alone and the new one gets a trailing underscore (src/cn.c:320-360) */
+static void output_path(char *out, size_t cap, const char *cond, const char *hc, const char *arc,
+                        int block_id, bool overwrite)
+{
+    snprintf(out, cap, "cn_rasters_%s/cn_%s_%s_%d.tif", cond, hc, arc, block_id);  /* src/cn.c:308 */
+    if (!overwrite) {
+        FILE *f = fopen(out, "r");
+
+        if (f) {
+            fclose(f);
+            snprintf(out, cap, "cn_rasters_%s/cn_%s_%s_%d_.tif", cond, hc, arc, block_id); /* :341 */
+        }
+    }
+}
+
+/* returns 0 (done or skipped like the reference skips) or -1 for errors the
+ * reference answers with MPI_Abort */
+static int process_block(struct worker *w, int block_id)
+{
+    struct run *r = w->run;
+    const struct gcn10_gpu_api *g = r->gpu;
+    char err[1024] = "";
+    double esa_t[6], soil_t[6], gt[6], soil_gt[6];
+    int esa_rx, esa_ry, soil_rx, soil_ry;
+    int xoff, yoff, W, H, sxoff, syoff, hsx, hsy;
+    uint8_t *coarse = NULL;
+    int32_t *ci = NULL, *cj = NULL;
+    gcn10_tiff_writer *tifs[GCN10_N_RASTERS] = { 0 };
+    int rc = 0, bi, n_strips;
+    bool ok = false;
+
+    /* block geometry: attribute filter "ID"=<id>, first feature (src/cn.c:162-184) */
+    bi = gcn10_blocks_find(&r->blocks, block_id);
+    if (bi < 0) {
+        wlog(w, "ERROR", true, "block %d not found", block_id);                 /* src/cn.c:173 */
+        return 0;
+    }
+
+    /* landcover window (src/cn.c:187-192, src/raster.c:126-162) */
+    gcn10_raster_info(w->esa, &esa_rx, &esa_ry, esa_t);
+    if (gcn10_raster_window(esa_t, esa_rx, esa_ry, r->blocks.bbox[bi], &xoff, &yoff, &W, &H, gt) != 0) {
+        wlog(w, "ERROR", true, "invalid raster bounds for %s", r->cfg.esa_data_path);   /* src/raster.c:143 */
+        wlog(w, "ERROR", true, "esa load failed for block %d", block_id);               /* src/cn.c:189 */
+        return 0;
+    }
+    /* soil window (src/cn.c:195-203) */
+    gcn10_raster_info(w->soil, &soil_rx, &soil_ry, soil_t);
+    if (gcn10_raster_window(soil_t, soil_rx, soil_ry, r->blocks.bbox[bi], &sxoff, &syoff, &hsx, &hsy,
+                            soil_gt) != 0) {
+        wlog(w, "ERROR", true, "invalid raster bounds for %s", r->cfg.hysogs_data_path);
+        wlog(w, "ERROR", true, "hysogs load failed for block %d", block_id);            /* src/cn.c:198 */
+        return 0;
+    }
+    if ((long long)W * (long long)H > INT_MAX) {
+        /* the reference's int npix (src/cn.c:208) overflows here; refuse instead */
+        wlog(w, "ERROR", true, "block %d: %d x %d pixels exceed 2^31-1", block_id, W, H);
+        return 0;
+    }
+    coarse = malloc((size_t)hsx * (size_t)hsy);
+    ci = malloc((size_t)W * sizeof *ci);
+    cj = malloc((size_t)H * sizeof *cj);
+    if (!coarse || !ci || !cj) {
+        wlog(w, "ERROR", true, "malloc failed for hysogs resampling, block %d", block_id); /* src/cn.c:211 */
+        rc = -1;
+        goto out;
+    }
+    if (gcn10_raster_read(w->soil, sxoff, syoff, hsx, hsy, coarse, err, sizeof err) != 0) {
+        wlog(w, "ERROR", true, "%s", err);
+        wlog(w, "ERROR", true, "hysogs load failed for block %d", block_id);
+        goto out;
+    }
+    gcn10_build_index_maps(gt, soil_gt, W, H, hsx, hsy, ci, cj);       /* src/cn.c:218-229 */
+
+    /* output directories (src/cn.c:237-256) and the 18 files */
+    for (int c = 0; c < 2 && !r->null_sink; c++) {
+        char dir[64];
+
+        snprintf(dir, sizeof dir, "cn_rasters_%s", gcn10_conds[c]);
+        if (mkdir(dir, 0755) != 0 && errno != EEXIST) {
+            wlog(w, "ERROR", true, "failed to create output directory %s", dir);       /* src/cn.c:250 */
+            rc = -1;
+            goto out;
+        }
+    }
+    for (int k = 0; k < GCN10_N_RASTERS && !r->null_sink; k++) {
+        char path[PATH_MAX];
+
+        output_path(path, sizeof path, gcn10_conds[k / 9], gcn10_hcs[(k % 9) / 3], gcn10_arcs[k % 3],
+                    block_id, r->opt.overwrite);
+        tifs[k] = gcn10_tiff_create(path, W, H, gt, gcn10_raster_georef(w->esa), err, sizeof err);
+        if (!tifs[k]) {
+            wlog(w, "ERROR", true, "%s", err);          /* save_raster logs and goes on, src/raster.c:220-223 */
+            goto out;
+        }
+    }
+
+    /* device side of the block */
+    if (ensure_strip_buffers(w, W) != 0 ||
+        ensure_dev(w, (void **)&w->d_coarse, &w->coarse_cap, (size_t)hsx * hsy) != 0 ||
+        ensure_dev(w, (void **)&w->d_ci, &w->ci_cap, (size_t)W * 4) != 0 ||
+        ensure_dev(w, (void **)&w->d_cj, &w->cj_cap, (size_t)H * 4) != 0) {
+        rc = -1;
+        goto out;
+    }
+    atomic_store(&w->failed, false);
+    if (g->memcpy_h2d(w->ctx, w->d_coarse, coarse, (size_t)hsx * hsy, w->s_kernel) != 0 ||
+        g->memcpy_h2d(w->ctx, w->d_ci, ci, (size_t)W * 4, w->s_kernel) != 0 ||
+        g->memcpy_h2d(w->ctx, w->d_cj, cj, (size_t)H * 4, w->s_kernel) != 0 ||
+        g->prepare_tile(w->ctx, w->d_coarse, hsx, hsy, w->d_ci, W, w->s_kernel) != 0 ||
+        g->stream_sync(w->ctx, w->s_kernel) != 0) {    /* host arrays are pageable: finish before reuse */
+        wlog(w, "ERROR", true, "gpu: %s", g->last_error());
+        rc = -1;
+        goto out;
+    }
+
+    /* strips: rows are multiples of 256 (whole GeoTIFF tile rows) and of 16
+     * (16-byte aligned strip starts for any W) */
+    n_strips = (H + r->strip_rows - 1) / r->strip_rows;
+    for (int s = 0; s < n_strips; s++) {
+        struct strip_buf *b = &w->buf[s % NBUF];
+        int y0 = s * r->strip_rows;
+        int rows = H - y0 < r->strip_rows ? H - y0 : r->strip_rows;
+        size_t px = (size_t)W * (size_t)rows;
+        uint8_t *outs[GCN10_N_RASTERS];
+
+        /* this buffer's previous strip: its D2H must be done and handed to the sink,
+         * and the sink must be done with the pinned buffers */
+        if (drain_strip(w, b, tifs, W, H) != 0) {
+            rc = -1;
+            goto out;
+        }
+        wait_sink(b);
+
+        /* landcover rows straight into the pinned strip (replaces the malloc +
+         * GDALRasterIO of src/raster.c:169-178) */
+        if (gcn10_raster_read(w->esa, xoff, yoff + y0, W, rows, b->h_esa, err, sizeof err) != 0) {
+            wlog(w, "ERROR", true, "%s", err);
+            wlog(w, "ERROR", true, "esa load failed for block %d", block_id);
+            goto out;
+        }
+        if (g->memcpy_h2d(w->ctx, b->d_esa, b->h_esa, px, w->s_h2d) != 0 ||
+            g->event_record(w->ctx, b->ev_h2d, w->s_h2d) != 0 ||
+            g->stream_wait_event(w->ctx, w->s_kernel, b->ev_h2d) != 0)
+            goto gpu_fail;
+        for (int k = 0; k < GCN10_N_RASTERS; k++)
+            outs[k] = b->d_out[k];
+        if (g->cn_strip(w->ctx, b->d_esa, W, rows, w->d_cj + y0,
+                        GCN10_COND_DRAINED | GCN10_COND_UNDRAINED, 0x1ffu, outs, w->s_kernel) != 0 ||
+            g->event_record(w->ctx, b->ev_kernel, w->s_kernel) != 0 ||
+            g->stream_wait_event(w->ctx, w->s_d2h, b->ev_kernel) != 0)
+            goto gpu_fail;
+        for (int k = 0; k < GCN10_N_RASTERS; k++)
+            if (g->memcpy_d2h(w->ctx, b->h_out[k], b->d_out[k], px, w->s_d2h) != 0)
+                goto gpu_fail;
+        if (g->event_record(w->ctx, b->ev_d2h, w->s_d2h) != 0)
+            goto gpu_fail;
+        b->d2h_issued = true;
+        b->y0 = y0;
+        b->rows = rows;
+
+        /* while this strip is in flight, hand the previous one to the sink */
+        if (s > 0 && drain_strip(w, &w->buf[(s - 1) % NBUF], tifs, W, H) != 0) {
+            rc = -1;
+            goto out;
+        }
+    }
+    for (int i = 0; i < NBUF; i++)
+        if (drain_strip(w, &w->buf[i], tifs, W, H) != 0) {
+            rc = -1;
+            goto out;
+        }
+    for (int i = 0; i < NBUF; i++)
+        wait_sink(&w->buf[i]);
+    ok = !atomic_load(&w->failed);
+    goto out;
+
+gpu_fail:
+    wlog(w, "ERROR", true, "gpu: %s", g->last_error());
+    rc = -1;
+
+out:
+    /* nothing of this block may still be in flight when its buffers are reused */
+    for (int i = 0; i < NBUF; i++) {
+        if (w->buf[i].d2h_issued) {
+            g->event_sync(w->ctx, w->buf[i].ev_d2h);
+            w->buf[i].d2h_issued = false;
+        }
+        wait_sink(&w->buf[i]);
+    }
+    if (rc != 0 && w->ctx)
+        g->device_sync(w->ctx);
+    for (int k = 0; k < GCN10_N_RASTERS; k++) {
+        if (!tifs[k])
+            continue;
+        if (ok) {
+            if (gcn10_tiff_finish(tifs[k], err, sizeof err) != 0) {
+                wlog(w, "ERROR", true, "%s", err);      /* "write error %d on %s", src/raster.c:221 */
+            }
+        }
+        else {
+            gcn10_tiff_abort(tifs[k]);
+        }
+        tifs[k] = NULL;
+    }
+    if (ok || (r->null_sink && rc == 0 && !atomic_load(&w->failed))) {
+        for (int k = 0; k < GCN10_N_RASTERS; k++) {
+            /* src/cn.c:366-373: one completion line and one progress line per raster */
+            wlog(w, "INFO", false, "completed condition for %d: %s/%s/%s", block_id, gcn10_conds[k / 9],
+                 gcn10_hcs[(k % 9) / 3], gcn10_arcs[k % 3]);
+            {
+                char line[256];
+
+                snprintf(line, sizeof line, "progress: completed block %d / total %d", block_id,
+                         r->n_blocks);                                  /* src/log.c:203-206 */
+                gcn10_log_message(r->workers[0].log, "INFO", line, false);
+            }
+        }
+    }
+    free(coarse);
+    free(ci);
+    free(cj);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------ */
+/* workers and the run: src/main.c:58-203                                    */
+/* ------------------------------------------------------------------------ */
+
+static void worker_teardown(struct worker *w)
+{
+    const struct gcn10_gpu_api *g = w->run->gpu;
+
+    if (w->ctx) {
+        g->device_sync(w->ctx);
+        free_strip_buffers(w);
+        for (int i = 0; i < NBUF; i++) {
+            struct strip_buf *b = &w->buf[i];
+
+            if (b->ev_h2d) g->event_destroy(w->ctx, b->ev_h2d);
+            if (b->ev_kernel) g->event_destroy(w->ctx, b->ev_kernel);
+            if (b->ev_d2h) g->event_destroy(w->ctx, b->ev_d2h);
+        }
+        if (w->d_coarse) g->free(w->ctx, w->d_coarse);
+        if (w->d_ci) g->free(w->ctx, w->d_ci);
+        if (w->d_cj) g->free(w->ctx, w->d_cj);
+        if (w->s_h2d) g->stream_destroy(w->ctx, w->s_h2d);
+        if (w->s_kernel) g->stream_destroy(w->ctx, w->s_kernel);
+        if (w->s_d2h) g->stream_destroy(w->ctx, w->s_d2h);
+        g->destroy(w->ctx);
+        w->ctx = NULL;
+    }
+    gcn10_raster_close(w->esa);
+    gcn10_raster_close(w->soil);
+    w->esa = w->soil = NULL;
+    for (int i = 0; i < NBUF; i++) {
+        pthread_mutex_destroy(&w->buf[i].mu);
+        pthread_cond_destroy(&w->buf[i].cv);
+    }
+}
+
+static int worker_setup(struct worker *w)
+{
+    struct run *r = w->run;
+    const struct gcn10_gpu_api *g = r->gpu;
+    char err[1024];
+
+    for (int i = 0; i < NBUF; i++) {
+        pthread_mutex_init(&w->buf[i].mu, NULL);
+        pthread_cond_init(&w->buf[i].cv, NULL);
+    }
+    if (g->init(w->rank, &w->ctx) != 0) {
+        wlog(w, "ERROR", true, "gpu %d: %s", w->rank, g->last_error());
+        return -1;
+    }
+    GPU_TRY(w, g->set_tables(w->ctx, &r->tables[0][0][0], 9));
+    GPU_TRY(w, g->stream_create(w->ctx, &w->s_h2d));
+    GPU_TRY(w, g->stream_create(w->ctx, &w->s_kernel));
+    GPU_TRY(w, g->stream_create(w->ctx, &w->s_d2h));
+    for (int i = 0; i < NBUF; i++) {
+        GPU_TRY(w, g->event_create(w->ctx, &w->buf[i].ev_h2d));
+        GPU_TRY(w, g->event_create(w->ctx, &w->buf[i].ev_kernel));
+        GPU_TRY(w, g->event_create(w->ctx, &w->buf[i].ev_d2h));
+    }
+    /* the reference reopens both rasters for every block (src/raster.c:119);
+     * here each worker keeps its own handles */
+    w->esa = gcn10_raster_open(r->cfg.esa_data_path, r->cfg.esa_tile_dir, err, sizeof err);
+    if (!w->esa)
+        wlog(w, "ERROR", true, "%s", err);              /* "gdal open failed: ..." */
+    w->soil = gcn10_raster_open(r->cfg.hysogs_data_path, NULL, err, sizeof err);
+    if (!w->soil)
+        wlog(w, "ERROR", true, "%s", err);
+    return 0;
+}
+
+static void *worker_main(void *arg)
+{
+    struct worker *w = arg;
+    struct run *r = w->run;
+
+    if (worker_setup(w) != 0) {
+        atomic_store(&r->fatal, 1);
+        worker_teardown(w);
+        return NULL;
+    }
+    for (;;) {
+        int i = atomic_fetch_add(&r->next_block, 1);
+        int id;
+        double t0;
+
+        if (i >= r->n_blocks || atomic_load(&r->fatal))
+            break;
+        id = r->block_ids[i];
+        wlog(w, "INFO", true, "processing block %d", id);               /* src/main.c:172-173 */
+        if (!w->esa) {
+            wlog(w, "ERROR", true, "esa load failed for block %d", id); /* src/cn.c:189 */
+            continue;
+        }
+        if (!w->soil) {
+            wlog(w, "ERROR", true, "hysogs load failed for block %d", id);
+            continue;
+        }
+        t0 = now_seconds();
+        if (process_block(w, id) != 0) {
+            atomic_store(&r->fatal, 1);     /* where the reference calls MPI_Abort */
+            break;
+        }
+        w->busy_seconds += now_seconds() - t0;
+        w->blocks_done++;
+    }
+    worker_teardown(w);
+    return NULL;
+}
+
+struct row_error_ctx {
+    gcn10_log *log;
+};
+
+static void on_lookup_row_error(void *user, const char *message)
+{
+    struct row_error_ctx *c = user;
+
+    gcn10_log_message(c->log, "ERROR", message, true);     /* src/cn.c:61, 71, 81 */
+}
+
+int gcn10_run(const gcn10_run_options *opt)
+{
+    struct run *r = calloc(1, sizeof *r);
+    char err[2048] = "";
+    char msg[8192];
+    gcn10_log *log0 = NULL;
+    int exit_code = 1, n_dev, failed_k = -1, rc;
+    const char *sink = getenv("GCN10_SINK");
+    double t_start = now_seconds();
+
+    if (!r) {
+        fprintf(stderr, "out of memory\n");
+        return 1;
+    }
+    r->opt = *opt;
+    if (!opt->config_path) {
+        fprintf(stderr, "[rank 0] missing -c/--config <file>; see 'gcn10 -h' for usage.\n");   /* src/main.c:103-106 */
+        free(r);
+        return 1;
+    }
+    rc = gcn10_config_parse(opt->config_path, &r->cfg, err, sizeof err);
+    if (rc != 0) {
+        fprintf(stderr, "%s\n", err);                   /* src/config.c:52, 109-111 */
+        free(r);
+        return 1;
+    }
+    r->null_sink = sink && strcmp(sink, "null") == 0;
+    r->strip_rows = r->cfg.strip_rows > 0 ? r->cfg.strip_rows : DEFAULT_STRIP_ROWS;
+    r->strip_rows = (r->strip_rows + TILE - 1) / TILE * TILE;
+    r->deflate_level = r->cfg.deflate_level;
+
+    /* GPUs: one worker ("rank") each */
+    r->gpu = gcn10_gpu_api_get(err, sizeof err);
+    if (!r->gpu) {
+        fprintf(stderr, "[rank 0] %s\n", err);
+        goto done;
+    }
+    n_dev = r->gpu->device_count();
+    if (n_dev <= 0) {
+        fprintf(stderr, "[rank 0] no MI355X (gfx950) device visible; the CN path has no CPU fallback\n");
+        goto done;
+    }
+    r->n_workers = opt->gpus > 0 ? opt->gpus : (r->cfg.gpus > 0 ? r->cfg.gpus : n_dev);
+    if (r->n_workers > n_dev)
+        r->n_workers = n_dev;
+    r->workers = calloc((size_t)r->n_workers, sizeof *r->workers);
+    if (!r->workers)
+        goto done;
+
+    log0 = gcn10_log_open(r->cfg.log_dir, 0);           /* init_logging(rank), src/main.c:129 */
+    r->workers[0].log = log0;
+    snprintf(msg, sizeof msg,
+             "starting processing with %d gpu workers (ranks)\n"
+             "check rank_0.log in the log directory for detailed progress\n"
+             "config loaded:\n"
+             "  hysogs_data_path   = %s\n"
+             "  esa_data_path      = %s\n"
+             "  blocks_shp_path    = %s\n"
+             "  lookup_table_path  = %s\n"
+             "  log_dir            = %s",                /* src/main.c:114-125 */
+             r->n_workers, r->cfg.hysogs_data_path, r->cfg.esa_data_path, r->cfg.blocks_shp_path,
+             r->cfg.lookup_table_path, r->cfg.log_dir);
+    gcn10_log_message(log0, "INFO", msg, true);
+    for (int i = 1; i < r->n_workers; i++)
+        r->workers[i].log = gcn10_log_open(r->cfg.log_dir, i);
+    for (int i = 0; i < r->n_workers; i++) {
+        r->workers[i].run = r;
+        r->workers[i].rank = i;
+    }
+
+    /* the block index is needed for bboxes in either mode */
+    if (gcn10_blocks_open(r->cfg.blocks_shp_path, &r->blocks, err, sizeof err) != 0) {
+        gcn10_log_message(log0, "ERROR", err, true);    /* "ogr open failed: ..." */
+        if (!opt->blocks_file) {
+            snprintf(msg, sizeof msg, "failed to read shapefile %s", r->cfg.blocks_shp_path);  /* src/main.c:143 */
+            gcn10_log_message(log0, "ERROR", msg, true);
+            goto done;
+        }
+        /* list mode: every block then fails like the reference's per-block OGROpen (src/cn.c:156-160) */
+    }
+    if (opt->blocks_file) {
+        r->block_ids = gcn10_read_block_list(opt->blocks_file, &r->n_blocks);
+        if (!r->block_ids) {
+            snprintf(msg, sizeof msg, "cannot open block list file %s", opt->blocks_file);    /* src/raster.c:33 */
+            gcn10_log_message(log0, "ERROR", msg, true);
+        }
+        if (!r->block_ids || !r->n_blocks) {
+            snprintf(msg, sizeof msg, "no ids found in %s", opt->blocks_file);                /* src/main.c:135 */
+            gcn10_log_message(log0, "ERROR", msg, true);
+            goto done;
+        }
+    }
+    else {
+        /* every "ID" of the shapefile (what get_all_blocks is meant to return,
+         * src/raster.c:94-101; its `ids[*n_blocks++]` never gets that far) */
+        r->n_blocks = r->blocks.n;
+        r->block_ids = malloc((size_t)(r->n_blocks ? r->n_blocks : 1) * sizeof *r->block_ids);
+        if (r->block_ids)
+            memcpy(r->block_ids, r->blocks.id, (size_t)r->n_blocks * sizeof *r->block_ids);
+        if (!r->block_ids || !r->n_blocks) {
+            snprintf(msg, sizeof msg, "no blocks found in %s", r->cfg.blocks_shp_path);       /* src/main.c:148 */
+            gcn10_log_message(log0, "ERROR", msg, true);
+            goto done;
+        }
+    }
+
+    /* the nine lookup tables, once (the reference re-reads one per raster, src/cn.c:261) */
+    {
+        struct row_error_ctx ctx = { log0 };
+
+        rc = gcn10_load_all_lookup_tables(r->cfg.lookup_table_path, r->tables, &failed_k,
+                                          on_lookup_row_error, &ctx);
+        if (rc != 0) {
+            const char *hc = gcn10_hcs[failed_k / 3], *arc = gcn10_arcs[failed_k % 3];
+
+            if (rc == -2)
+                snprintf(msg, sizeof msg, "empty lookup table %s/default_lookup_%s_%s.csv",   /* src/cn.c:44 */
+                         r->cfg.lookup_table_path, hc, arc);
+            else if (rc == -3)
+                snprintf(msg, sizeof msg, "lookup table path too long: %s/default_lookup_%s_%s.csv", /* :23 */
+                         r->cfg.lookup_table_path, hc, arc);
+            else
+                snprintf(msg, sizeof msg, "cannot open lookup table %s/default_lookup_%s_%s.csv",    /* :30 */
+                         r->cfg.lookup_table_path, hc, arc);
+            gcn10_log_message(log0, "ERROR", msg, true);
+            goto done;
+        }
+    }
+
+    snprintf(msg, sizeof msg, "processing %d blocks %s", r->n_blocks,
+             opt->blocks_file ? "from list file" : "from shapefile");      /* src/main.c:165-167 */
+    gcn10_log_message(log0, "INFO", msg, true);
+
+    if (!r->null_sink) {
+        long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+        int nthreads = r->cfg.io_threads > 0 ? r->cfg.io_threads : (int)(ncpu > 2 ? ncpu - 1 : 1);
+
+        if (nthreads > 64)
+            nthreads = 64;
+        r->pool = gcn10_pool_create(nthreads);
+        if (!r->pool) {
+            gcn10_log_message(log0, "ERROR", "cannot start the tile compression threads", true);
+            goto done;
+        }
+    }
+
+    atomic_store(&r->next_block, 0);
+    atomic_store(&r->fatal, 0);
+    for (int i = 0; i < r->n_workers; i++)
+        if (pthread_create(&r->workers[i].thread, NULL, worker_main, &r->workers[i]) != 0) {
+            gcn10_log_message(log0, "ERROR", "cannot start a gpu worker thread", true);
+            atomic_store(&r->fatal, 1);
+            r->n_workers = i;
+            break;
+        }
+    for (int i = 0; i < r->n_workers; i++)
+        pthread_join(r->workers[i].thread, NULL);      /* MPI_Barrier, src/main.c:187 */
+
+    snprintf(msg, sizeof msg, "processed %d blocks on %d ranks", r->n_blocks, r->n_workers);  /* src/main.c:191 */
+    gcn10_log_message(log0, "INFO", msg, true);
+    {
+        int done_blocks = 0;
+
+        for (int i = 0; i < r->n_workers; i++)
+            done_blocks += r->workers[i].blocks_done;
+        snprintf(msg, sizeof msg, "timing: %d blocks, %.3f s wall, %d gpu worker(s)%s", done_blocks,
+                 now_seconds() - t_start, r->n_workers, r->null_sink ? ", null sink" : "");
+        gcn10_log_message(log0, "INFO", msg, false);
+    }
+    exit_code = atomic_load(&r->fatal) ? 1 : 0;
+
+done:
+    gcn10_pool_destroy(r->pool);
+    if (r->workers) {
+        for (int i = 1; i < r->n_workers; i++)
+            gcn10_log_close(r->workers[i].log);
+    }
+    gcn10_log_close(log0);                              /* finalize_logging, src/main.c:197 */
+    free(r->workers);
+    free(r->block_ids);
+    gcn10_blocks_free(&r->blocks);
+    gcn10_config_free(&r->cfg);
+    free(r);
+    return exit_code;
+}

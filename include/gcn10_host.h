@@ -187,6 +187,29 @@ int gcn10_save_raster(const uint8_t *data, int xsize, int ysize, const double gt
                       const gcn10_georef *georef, const char *path, int level,
                       char *err, size_t errcap);
 
+
+/* ------------------------------------------------------------------------ */
+/* the run: src/main.c:58-203 + process_block, src/cn.c:134-384              */
+/* ------------------------------------------------------------------------ */
+
+typedef struct gcn10_run_options {
+    const char *config_path;    /* -c / --config (required)                      */
+    const char *blocks_file;    /* -l / -b / --blocks, NULL = every shapefile ID */
+    bool overwrite;             /* -o / --overwrite                              */
+    int gpus;                   /* --gpus N, 0 = config key "gpus" or all visible */
+} gcn10_run_options;
+
+/* Runs the whole job: config, logs, block ids, lookup tables, one worker thread
+ * per GPU pulling block ids from a shared atomic counter (replaces the static
+ * round-robin over MPI ranks, src/main.c:171), per block: windows, index maps,
+ * pinned-host strips double-buffered against the fused kernel, 18 tiled DEFLATE
+ * GeoTIFFs named as src/cn.c:308, 341.  Returns the process exit code: 0, or 1
+ * where the reference calls MPI_Abort(.., 1). */
+int gcn10_run(const gcn10_run_options *opt);
+
+/* Path of the HIP library this process would load (diagnostics). */
+const char *gcn10_gpu_library_path(void);
+
 #ifdef __cplusplus
 }
 #endif

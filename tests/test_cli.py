@@ -1,0 +1,163 @@
+"""The gcn10 program end to end: same CLI / config / shapefile / CSV interfaces as the
+reference's src/ program, outputs compared (decoded pixels + georeferencing) with the oracle."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from oracle import cn_oracle_c as oc
+from tests import tiffutil
+from tests.conftest import LOOKUPS, ROOT
+from tests.util import ESA_NASTY, HSG_NASTY
+
+GCN10 = os.path.join(ROOT, "bin", "gcn10")
+CONDS, HCS, ARCS = ("drained", "undrained"), ("p", "f", "g"), ("i", "ii", "iii")
+
+ESA_GT = [10.0, 0.001, 0.0, 50.0, 0.0, -0.001]          # 3000 x 2000 px: lon 10..13, lat 48..50
+SOIL_GT = [9.9875, 0.025, 0.0, 50.0125, 0.0, -0.025]    # 25x coarser, origin half a cell off
+BLOCKS = [(101, 10.0, 49.0, 11.0, 50.0),     # inside
+          (102, 11.0, 48.0, 12.0, 49.0),     # inside
+          (103, 12.5, 47.5, 13.5, 48.5),     # sticks out east and south: clamped window
+          (104, 20.0, 20.0, 21.0, 21.0)]     # outside the rasters: "invalid raster bounds"
+
+
+def _world(tmp_path, seed=5):
+    rng = np.random.default_rng(seed)
+    small = rng.choice(ESA_NASTY, size=(2000 // 20, 3000 // 20))
+    esa = np.repeat(np.repeat(small, 20, axis=0), 20, axis=1)
+    noise = rng.integers(0, 256, size=esa.shape, dtype=np.uint8)
+    esa = np.where(noise < 30, rng.choice(ESA_NASTY, size=esa.shape), esa).astype(np.uint8)
+    soil = rng.choice(HSG_NASTY, size=(2000 // 25 + 2, 3000 // 25 + 2)).astype(np.uint8)
+    tiffutil.write_tiff(str(tmp_path / "esa.tif"), esa, gt=ESA_GT, compression=8, tile=(512, 512))
+    tiffutil.write_tiff(str(tmp_path / "soil_lzw.tif"), soil, gt=SOIL_GT, compression=5, rows_per_strip=8)
+    tiffutil.write_block_shapefile(str(tmp_path / "blocks"), BLOCKS)
+    (tmp_path / "config.txt").write_text(
+        "# test config\nhysogs_data_path=%s\nesa_data_path=%s\nblocks_shp_path=%s\n"
+        "lookup_table_path=%s\nlog_dir=%s\nstrip_rows=256\nio_threads=4\n"
+        % (tmp_path / "soil_lzw.tif", tmp_path / "esa.tif", tmp_path / "blocks.shp", LOOKUPS, tmp_path / "logs"))
+    return esa, soil
+
+
+def _run(tmp_path, *args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([GCN10, *args], cwd=str(tmp_path), capture_output=True, text=True, env=e,
+                          timeout=600)
+
+
+def test_help_and_version_need_nothing():
+    out = subprocess.run([GCN10, "--version"], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout == "gcn10 0.1.0\n"        # src/main.c:51
+    out = subprocess.run([GCN10, "-h"], capture_output=True, text=True)
+    assert out.returncode == 0 and "--config, -c <file>" in out.stdout and "--overwrite, -o" in out.stdout
+
+
+def test_missing_config_argument_and_file(tmp_path):
+    out = _run(tmp_path)
+    assert out.returncode == 1 and "missing -c/--config <file>" in out.stderr     # src/main.c:103-108
+    out = _run(tmp_path, "-c", "nope.txt")
+    assert out.returncode == 1 and "cannot open config 'nope.txt'" in out.stderr  # src/config.c:52
+    (tmp_path / "c.txt").write_text("esa_data_path=x\n")
+    out = _run(tmp_path, "-c", "c.txt")
+    assert out.returncode == 1 and "missing one of: hysogs_data_path" in out.stderr
+
+
+def test_no_gpu_means_no_run(tmp_path):
+    from gcn10_amd import gpu
+    if gpu.device_count() > 0:
+        pytest.skip("a GPU is present")
+    _world(tmp_path)
+    out = _run(tmp_path, "-c", "config.txt")
+    assert out.returncode == 1
+    assert "no CPU fallback" in out.stderr
+    assert not (tmp_path / "cn_rasters_drained").exists()
+
+
+@pytest.mark.gpu
+def test_blocks_equal_oracle_and_reference_conventions(tmp_path, tables):
+    esa, soil = _world(tmp_path)
+    (tmp_path / "ids.txt").write_text("101 102\n103\n104 999\n")
+    out = _run(tmp_path, "-c", "config.txt", "-l", "ids.txt")
+    assert out.returncode == 0, out.stderr[-2000:]
+    log = (tmp_path / "logs" / "rank_0.log").read_text()
+    assert "processing 5 blocks from list file" in log                           # src/main.c:165
+    assert "[ERROR] [rank 0] invalid raster bounds for" in log                    # block 104, src/raster.c:143
+    assert "[ERROR] [rank 0] esa load failed for block 104" in log                # src/cn.c:189
+    assert "[ERROR] [rank 0] block 999 not found" in log                          # src/cn.c:173
+    assert "processed 5 blocks on 1 ranks" in log                                 # src/main.c:191
+    assert len(re.findall(r"completed condition for 101: ", log)) == 18           # src/cn.c:367
+    assert len(re.findall(r"progress: completed block 101 / total 5", log)) == 18  # src/log.c:203, 18x
+    assert "completed condition for 101: drained/p/i" in log and \
+        "completed condition for 101: undrained/g/iii" in log
+
+    for bid, *bbox in BLOCKS[:3]:
+        xo, yo, W, H, gt = oc.window(ESA_GT, 3000, 2000, bbox)
+        sxo, syo, hsx, hsy, sgt = oc.window(SOIL_GT, soil.shape[1], soil.shape[0], bbox)
+        want = oc.process_block_mem(esa[yo:yo + H, xo:xo + W], gt, soil[syo:syo + hsy, sxo:sxo + hsx],
+                                    sgt, tables)
+        if bid == 103:
+            assert (W, H) == (500, 500)           # clamped at the east / south edge
+        for c, cond in enumerate(CONDS):
+            for hi, hc in enumerate(HCS):
+                for ai, arc in enumerate(ARCS):
+                    p = tmp_path / ("cn_rasters_%s" % cond) / ("cn_%s_%s_%d.tif" % (hc, arc, bid))  # src/cn.c:308
+                    im = Image.open(str(p))
+                    assert np.array_equal(np.array(im), want[c * 9 + hi * 3 + ai]), p
+                    t = im.tag_v2
+                    assert t[259] == 8 and t[322] == 256 and t[323] == 256        # src/raster.c:206-207
+                    assert tuple(t[33550]) == (gt[1], -gt[5], 0.0)                # clipped ESA gt, src/raster.c:157-162
+                    assert tuple(t[33922]) == (0.0, 0.0, 0.0, gt[0], gt[3], 0.0)
+                    assert 4326 in t[34735]
+    assert not (tmp_path / "cn_rasters_drained" / "cn_p_i_104.tif").exists()
+    assert sorted(os.listdir(tmp_path / "cn_rasters_undrained")) == sorted(
+        "cn_%s_%s_%d.tif" % (hc, arc, b) for hc in HCS for arc in ARCS for b in (101, 102, 103))
+
+
+@pytest.mark.gpu
+def test_overwrite_rule_and_shapefile_mode(tmp_path, tables):
+    esa, soil = _world(tmp_path, seed=9)
+    (tmp_path / "ids.txt").write_text("102\n")
+    assert _run(tmp_path, "-c", "config.txt", "-b", "ids.txt").returncode == 0      # -b as advertised, src/main.c:28
+    first = (tmp_path / "cn_rasters_drained" / "cn_f_i_102.tif").read_bytes()
+    # second run without -o: existing outputs stay, new ones get a trailing underscore (src/cn.c:320-360)
+    assert _run(tmp_path, "--config", "config.txt", "--blocks", "ids.txt").returncode == 0
+    assert (tmp_path / "cn_rasters_drained" / "cn_f_i_102.tif").read_bytes() == first
+    again = tmp_path / "cn_rasters_drained" / "cn_f_i_102_.tif"
+    assert again.exists() and np.array_equal(np.array(Image.open(str(again))),
+                                             np.array(Image.open(str(tmp_path / "cn_rasters_drained" / "cn_f_i_102.tif"))))
+    # with -o nothing new appears
+    n_before = len(os.listdir(tmp_path / "cn_rasters_drained"))
+    assert _run(tmp_path, "-c", "config.txt", "-l", "ids.txt", "-o").returncode == 0
+    assert len(os.listdir(tmp_path / "cn_rasters_drained")) == n_before
+    # no list: every ID of the shapefile (the mode that crashes in the reference)
+    out = _run(tmp_path, "-c", "config.txt", "-o")
+    assert out.returncode == 0
+    log = (tmp_path / "logs" / "rank_0.log").read_text()
+    assert "processing 4 blocks from shapefile" in log
+    assert (tmp_path / "cn_rasters_undrained" / "cn_g_iii_103.tif").exists()
+
+
+@pytest.mark.gpu
+def test_broken_lookup_aborts_like_the_reference(tmp_path):
+    _world(tmp_path)
+    (tmp_path / "lk").mkdir()
+    for f in os.listdir(LOOKUPS):
+        if f != "default_lookup_g_ii.csv":
+            (tmp_path / "lk" / f).write_bytes(open(os.path.join(LOOKUPS, f), "rb").read())
+    cfg = (tmp_path / "config.txt").read_text().replace(LOOKUPS, str(tmp_path / "lk"))
+    (tmp_path / "config.txt").write_text(cfg)
+    out = _run(tmp_path, "-c", "config.txt")
+    assert out.returncode == 1                                                    # MPI_Abort(.., 1), src/cn.c:32
+    assert "cannot open lookup table" in out.stderr and "default_lookup_g_ii.csv" in out.stderr
+
+
+@pytest.mark.gpu
+def test_null_sink_runs_the_gpu_pipeline_without_files(tmp_path):
+    _world(tmp_path)
+    out = _run(tmp_path, "-c", "config.txt", env={"GCN10_SINK": "null"})
+    assert out.returncode == 0
+    assert not (tmp_path / "cn_rasters_drained").exists()
+    assert "completed condition for 101: drained/p/i" in (tmp_path / "logs" / "rank_0.log").read_text()
