@@ -55,7 +55,8 @@ struct strip_buf {
 
 struct worker {
     struct run *run;
-    int rank;                               /* GPU index = "rank" in the logs */
+    int rank;                               /* "rank" in the logs: outer_rank * n_workers + index */
+    int index;                              /* worker index in this process; GPU = index % n_devices */
     pthread_t thread;
     gcn10_log *log;
     gcn10_gpu_ctx *ctx;
@@ -88,6 +89,8 @@ struct run {
     int strip_rows;
     int deflate_level;
     bool null_sink;                         /* GCN10_SINK=null: no compression, no files */
+    int n_devices;                          /* visible GPUs; worker i uses device i % n_devices */
+    int outer_rank, outer_size;             /* this process among the processes of an mpirun / srun */
 };
 
 static double now_seconds(void)
@@ -537,8 +540,8 @@ static int worker_setup(struct worker *w)
         pthread_mutex_init(&w->buf[i].mu, NULL);
         pthread_cond_init(&w->buf[i].cv, NULL);
     }
-    if (g->init(w->rank, &w->ctx) != 0) {
-        wlog(w, "ERROR", true, "gpu %d: %s", w->rank, g->last_error());
+    if (g->init(w->index % r->n_devices, &w->ctx) != 0) {
+        wlog(w, "ERROR", true, "gpu %d: %s", w->index % r->n_devices, g->last_error());
         return -1;
     }
     GPU_TRY(w, g->set_tables(w->ctx, &r->tables[0][0][0], 9));
@@ -600,6 +603,30 @@ static void *worker_main(void *arg)
     return NULL;
 }
 
+/* Rank and size of this process when it was started by an MPI launcher or
+ * srun, read from the launcher's environment (Open MPI, MPICH/Hydra PMI,
+ * Slurm); no MPI library is linked.  Keeps `mpirun -n N gcn10 ...` meaningful
+ * across nodes: one process per node, each driving its node's GPUs. */
+static void outer_from_env(int *rank, int *size)
+{
+    static const char *const names[][2] = { { "OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_SIZE" },
+                                            { "PMI_RANK", "PMI_SIZE" },
+                                            { "PMIX_RANK", "PMIX_SIZE" },
+                                            { "SLURM_PROCID", "SLURM_NTASKS" } };
+
+    *rank = 0;
+    *size = 1;
+    for (size_t i = 0; i < sizeof names / sizeof names[0]; i++) {
+        const char *r = getenv(names[i][0]), *s = getenv(names[i][1]);
+
+        if (r && s && atoi(s) > 1 && atoi(r) >= 0 && atoi(r) < atoi(s)) {
+            *rank = atoi(r);
+            *size = atoi(s);
+            return;
+        }
+    }
+}
+
 struct row_error_ctx {
     gcn10_log *log;
 };
@@ -653,14 +680,19 @@ int gcn10_run(const gcn10_run_options *opt)
         fprintf(stderr, "[rank 0] no MI355X (gfx950) device visible; the CN path has no CPU fallback\n");
         goto done;
     }
+    r->n_devices = n_dev;
     r->n_workers = opt->gpus > 0 ? opt->gpus : (r->cfg.gpus > 0 ? r->cfg.gpus : n_dev);
-    if (r->n_workers > n_dev)
+    /* more workers than GPUs only on request (tests of the queue on a one-GPU box) */
+    if (r->n_workers > n_dev && !getenv("GCN10_OVERSUBSCRIBE"))
         r->n_workers = n_dev;
+    if (r->n_workers > 64)
+        r->n_workers = 64;
+    outer_from_env(&r->outer_rank, &r->outer_size);
     r->workers = calloc((size_t)r->n_workers, sizeof *r->workers);
     if (!r->workers)
         goto done;
 
-    log0 = gcn10_log_open(r->cfg.log_dir, 0);           /* init_logging(rank), src/main.c:129 */
+    log0 = gcn10_log_open(r->cfg.log_dir, r->outer_rank * r->n_workers);   /* init_logging(rank), src/main.c:129 */
     r->workers[0].log = log0;
     snprintf(msg, sizeof msg,
              "starting processing with %d gpu workers (ranks)\n"
@@ -675,10 +707,11 @@ int gcn10_run(const gcn10_run_options *opt)
              r->cfg.lookup_table_path, r->cfg.log_dir);
     gcn10_log_message(log0, "INFO", msg, true);
     for (int i = 1; i < r->n_workers; i++)
-        r->workers[i].log = gcn10_log_open(r->cfg.log_dir, i);
+        r->workers[i].log = gcn10_log_open(r->cfg.log_dir, r->outer_rank * r->n_workers + i);
     for (int i = 0; i < r->n_workers; i++) {
         r->workers[i].run = r;
-        r->workers[i].rank = i;
+        r->workers[i].index = i;
+        r->workers[i].rank = r->outer_rank * r->n_workers + i;
     }
 
     /* the block index is needed for bboxes in either mode */
@@ -743,6 +776,19 @@ int gcn10_run(const gcn10_run_options *opt)
     snprintf(msg, sizeof msg, "processing %d blocks %s", r->n_blocks,
              opt->blocks_file ? "from list file" : "from shapefile");      /* src/main.c:165-167 */
     gcn10_log_message(log0, "INFO", msg, true);
+
+    /* under mpirun / srun every process takes the reference's static share of the
+     * list, i = rank, rank + size, ... (src/main.c:171), and feeds its own GPUs */
+    if (r->outer_size > 1) {
+        int kept = 0;
+
+        for (int i = r->outer_rank; i < r->n_blocks; i += r->outer_size)
+            r->block_ids[kept++] = r->block_ids[i];
+        snprintf(msg, sizeof msg, "process %d of %d: %d of %d blocks", r->outer_rank, r->outer_size,
+                 kept, r->n_blocks);
+        gcn10_log_message(log0, "INFO", msg, true);
+        r->n_blocks = kept;
+    }
 
     if (!r->null_sink) {
         long ncpu = sysconf(_SC_NPROCESSORS_ONLN);

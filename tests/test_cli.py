@@ -161,3 +161,40 @@ def test_null_sink_runs_the_gpu_pipeline_without_files(tmp_path):
     assert out.returncode == 0
     assert not (tmp_path / "cn_rasters_drained").exists()
     assert "completed condition for 101: drained/p/i" in (tmp_path / "logs" / "rank_0.log").read_text()
+
+
+@pytest.mark.gpu
+def test_several_workers_share_the_block_queue(tmp_path, tables):
+    """Three worker threads ("ranks") on the one GPU of the test box pull from the same
+    atomic block counter; every block is produced exactly once, bit-identical."""
+    esa, soil = _world(tmp_path, seed=21)
+    out = _run(tmp_path, "-c", "config.txt", "--gpus", "3", env={"GCN10_OVERSUBSCRIBE": "1"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    logs = [(tmp_path / "logs" / ("rank_%d.log" % i)).read_text() for i in range(3)]
+    assert "starting processing with 3 gpu workers" in logs[0]
+    started = sum(len(re.findall(r"processing block \d+", l)) for l in logs)
+    assert started == 4                                           # each block taken once
+    for bid, *bbox in BLOCKS[:3]:
+        xo, yo, W, H, gt = oc.window(ESA_GT, 3000, 2000, bbox)
+        sxo, syo, hsx, hsy, sgt = oc.window(SOIL_GT, soil.shape[1], soil.shape[0], bbox)
+        want = oc.process_block_mem(esa[yo:yo + H, xo:xo + W], gt, soil[syo:syo + hsy, sxo:sxo + hsx],
+                                    sgt, tables)
+        for r in (0, 7, 17):
+            c, k = divmod(r, 9)
+            p = tmp_path / ("cn_rasters_%s" % CONDS[c]) / ("cn_%s_%s_%d.tif" % (HCS[k // 3], ARCS[k % 3], bid))
+            assert np.array_equal(np.array(Image.open(str(p))), want[r])
+
+
+@pytest.mark.gpu
+def test_outer_launcher_ranks_take_round_robin_shares(tmp_path):
+    """Started by mpirun / srun, process r of n takes blocks r, r+n, ... (src/main.c:171)."""
+    _world(tmp_path, seed=22)
+    (tmp_path / "ids.txt").write_text("101 102 103\n")
+    for rank in (0, 1):
+        out = _run(tmp_path, "-c", "config.txt", "-l", "ids.txt", env={"PMI_RANK": str(rank), "PMI_SIZE": "2"})
+        assert out.returncode == 0, out.stderr[-2000:]
+    log0 = (tmp_path / "logs" / "rank_0.log").read_text()
+    log1 = (tmp_path / "logs" / "rank_1.log").read_text()
+    assert "process 0 of 2: 2 of 3 blocks" in log0 and "process 1 of 2: 1 of 3 blocks" in log1
+    assert "processing block 101" in log0 and "processing block 103" in log0 and "processing block 102" in log1
+    assert len(os.listdir(tmp_path / "cn_rasters_drained")) == 27

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""End-to-end timing of bin/gcn10 on synthetic full-size blocks (BASELINE config 3/5 shape).
+
+Builds, under --workdir, an uncompressed tiled landcover GeoTIFF of N blocks of SIZE^2 pixels
+side by side, a 25x coarser LZW soil GeoTIFF and the block shapefile, then runs the program
+(a) with GCN10_SINK=null: file decode + pinned staging + H2D + fused kernel + D2H, no encode,
+(b) with the real sink: + 256x256 tile DEFLATE on the host pool + GeoTIFF files.
+Prints one JSON line.  PCIe-inclusive numbers for DESIGN.md; never bench.py's `value`.
+"""
+import argparse
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+import bench  # noqa: E402
+from tests import tiffutil  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=36000)
+    ap.add_argument("--blocks", type=int, default=2)
+    ap.add_argument("--workdir", default="/tmp/gcn10_pipeline_bench")
+    ap.add_argument("--strip-rows", type=int, default=1024)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--modes", default="null,files")
+    ap.add_argument("--pattern", default="patches")
+    ap.add_argument("--deflate-level", type=int, default=0)
+    a = ap.parse_args()
+    wd = a.workdir
+    shutil.rmtree(wd, ignore_errors=True)
+    os.makedirs(wd)
+    size, nb = a.size, a.blocks
+    px = 3.0 / size
+    t0 = time.time()
+    # landcover: nb blocks side by side (lon 0..3*nb, lat 0..3), written tile-wise without
+    # holding more than one block in memory
+    esa1, _, coarse1, _ = bench.synth_block(1, size, a.pattern)
+    esa = np.concatenate([esa1] * nb, axis=1) if nb > 1 else esa1
+    del esa1
+    tiffutil.write_tiff(os.path.join(wd, "esa.tif"), esa, gt=[0.0, px, 0.0, 3.0, 0.0, -px],
+                        compression=1, tile=(1024, 1024), bigtiff=esa.size > 3 * 2**30)
+    del esa
+    hs = coarse1.shape[0]
+    soil = np.concatenate([coarse1] * nb, axis=1) if nb > 1 else coarse1
+    tiffutil.write_tiff(os.path.join(wd, "soil.tif"), soil, gt=[0.0, 3.0 / hs, 0.0, 3.0, 0.0, -3.0 / hs],
+                        compression=8, rows_per_strip=64)
+    tiffutil.write_block_shapefile(os.path.join(wd, "blocks"),
+                                   [(i + 1, 3.0 * i, 0.0, 3.0 * (i + 1), 3.0) for i in range(nb)])
+    with open(os.path.join(wd, "config.txt"), "w") as f:
+        f.write("hysogs_data_path=%s/soil.tif\nesa_data_path=%s/esa.tif\nblocks_shp_path=%s/blocks.shp\n"
+                "lookup_table_path=%s\nlog_dir=%s/logs\nstrip_rows=%d\ndeflate_level=%d\n"
+                % (wd, wd, wd, os.path.join(ROOT, "tests", "golden", "lookups"), wd, a.strip_rows,
+                   a.deflate_level))
+    build_s = time.time() - t0
+    res = {"size": size, "blocks": nb, "strip_rows": a.strip_rows, "gpus": a.gpus, "pattern": a.pattern,
+           "world_build_seconds": round(build_s, 1), "modes": {}}
+    for mode in a.modes.split(","):
+        env = dict(os.environ)
+        if mode == "null":
+            env["GCN10_SINK"] = "null"
+        shutil.rmtree(os.path.join(wd, "logs"), ignore_errors=True)
+        t0 = time.time()
+        out = subprocess.run([os.path.join(ROOT, "bin", "gcn10"), "-c", "config.txt", "-o", "--gpus", str(a.gpus)],
+                             cwd=wd, env=env, capture_output=True, text=True)
+        wall = time.time() - t0
+        log = open(os.path.join(wd, "logs", "rank_0.log")).read() if os.path.exists(os.path.join(wd, "logs", "rank_0.log")) else ""
+        m = re.search(r"timing: (\d+) blocks, ([0-9.]+) s wall", log)
+        done = int(m.group(1)) if m else 0
+        secs = float(m.group(2)) if m else wall
+        nbytes = 0
+        for d in ("cn_rasters_drained", "cn_rasters_undrained"):
+            p = os.path.join(wd, d)
+            if os.path.isdir(p):
+                nbytes += sum(os.path.getsize(os.path.join(p, f)) for f in os.listdir(p))
+        res["modes"][mode] = {"rc": out.returncode, "blocks_done": done, "seconds": round(secs, 3),
+                              "cn_gpx_per_s": round(done * size * size * 18 / secs / 1e9, 3) if secs else None,
+                              "seconds_per_block": round(secs / done, 3) if done else None,
+                              "output_bytes": nbytes, "stderr_tail": out.stderr[-300:] if out.returncode else ""}
+    print(json.dumps(res))
+    shutil.rmtree(wd, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
