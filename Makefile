@@ -24,8 +24,9 @@ host: $(PKG)/libgcn10_host.so
 oracle:
 	$(MAKE) -C oracle
 
-$(PKG)/libgcn10_gpu.so: $(CSRC)/gcn10_gpu.hip include/gcn10_gpu.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $<
+GPUSRC := $(wildcard $(CSRC)/*.hip)
+$(PKG)/libgcn10_gpu.so: $(GPUSRC) $(CSRC)/gcn10_gpu_internal.hpp include/gcn10_gpu.h
+	$(HIPCC) $(HIPFLAGS) -I$(CSRC) -shared -o $@ $(GPUSRC)
 
 $(PKG)/libgcn10_host.so: $(HOSTLIBSRC) include/gcn10_host.h include/gcn10_gpu.h
 	$(CC) $(CFLAGS) -shared -o $@ $(HOSTLIBSRC) -lm -lz -ldl

@@ -32,30 +32,14 @@
 #include <new>
 
 #include "gcn10_gpu.h"
+#include "gcn10_gpu_internal.hpp"
+
+using gcn10::as_stream;
+using gcn10::fail;
+using gcn10::u32x4;
+using gcn10::use_device;
 
 namespace {
-
-// ------------------------------------------------------------------------
-// error plumbing
-// ------------------------------------------------------------------------
-thread_local char g_err[512] = "";
-
-int fail(int code, const char *fmt, ...)
-{
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof g_err, fmt, ap);
-    va_end(ap);
-    return code;
-}
-
-#define HIP_TRY(expr)                                                          \
-    do {                                                                       \
-        hipError_t e_ = (expr);                                                \
-        if (e_ != hipSuccess)                                                  \
-            return fail(e_ == hipErrorOutOfMemory ? GCN10_E_NOMEM : GCN10_E_HIP, \
-                        "%s: %s", #expr, hipGetErrorString(e_));               \
-    } while (0)
 
 // ------------------------------------------------------------------------
 // constants shared by host and device
@@ -73,7 +57,6 @@ constexpr int kLut16Bytes = kPlanes * kPlane16;
 constexpr int kPlane1 = 256 + 4;
 constexpr int kLut1Bytes = kPlanes * kPlane1;
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct StripParams {
     const uint8_t *esa;
@@ -193,26 +176,6 @@ __device__ __forceinline__ int32_t scalar_load_i32(const int32_t *base, uint32_t
     typedef const int32_t __attribute__((address_space(4))) *const_ptr_t;
     const_ptr_t cp = (const_ptr_t)(uintptr_t)base;
     return cp[__builtin_amdgcn_readfirstlane(i)];
-}
-
-// Split a flat strip index into (row, column).  `wave_base` is uniform over
-// the wave, so its division runs once per wave on uniform values; a lane only
-// divides again when its own 16 pixels start in a later row.
-__device__ __forceinline__ void flat_to_xy(uint32_t wave_base, uint32_t lane_off,
-                                           uint32_t W, uint32_t &y, uint32_t &x)
-{
-    uint32_t wb = __builtin_amdgcn_readfirstlane(wave_base);
-    uint32_t yb = wb / W;
-    uint32_t xb = wb - yb * W;
-    uint32_t xx = xb + lane_off;
-    uint32_t yy = yb;
-    if (xx >= W) {
-        uint32_t q = xx / W;
-        yy += q;
-        xx -= q * W;
-    }
-    y = yy;
-    x = xx;
 }
 
 // Workgroup -> chunk mapping.  Workgroups are dealt round-robin over the 8
@@ -672,31 +635,18 @@ inline int popcount(unsigned v)
 
 }  // namespace
 
-// ------------------------------------------------------------------------
-// context
-// ------------------------------------------------------------------------
-struct gcn10_gpu_ctx {
-    int device = -1;
-    int n_cus = 0;
-    hipStream_t main_stream = nullptr;
-    uint8_t *d_lut16 = nullptr;     // kLut16Bytes
-    uint8_t *d_lut1 = nullptr;      // 9 * kLut1Bytes
-    int n_tables = 0;
-    uint8_t *d_hx = nullptr;
-    size_t hx_capacity = 0;
-    uint32_t hx_stride = 0;
-    uint32_t hx_W = 0;
-    uint32_t hx_rows = 0;
-    const char *last_kernel = "";
-    // tuning knobs (gcn10_gpu_set_option); defaults = the round-1 measured best
-    int grid_blocks_per_cu = 8;
-    int ilp16 = 1;          // sub-chunks per loop trip, all-tables kernel (1, 2)
-    int ilp1 = 1;           // same, single-table kernel (1, 2, 4)
-    int nontemporal = 1;
-    int xcd_slabs = 1;
-};
+namespace gcn10 {
 
-namespace {
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
 
 int use_device(gcn10_gpu_ctx *ctx)
 {
@@ -706,10 +656,14 @@ int use_device(gcn10_gpu_ctx *ctx)
     return GCN10_OK;
 }
 
-inline hipStream_t as_stream(gcn10_gpu_ctx *ctx, gcn10_stream_t s)
+hipStream_t as_stream(gcn10_gpu_ctx *ctx, gcn10_stream_t s)
 {
     return s ? reinterpret_cast<hipStream_t>(s) : ctx->main_stream;
 }
+
+}  // namespace gcn10
+
+namespace {
 
 // Memory-bound streaming grid: a few workgroups per CU, each looping over
 // chunks; a multiple of 8 so every XCD gets the same number.
@@ -737,7 +691,7 @@ int gcn10_gpu_abi_version(void)
 
 const char *gcn10_gpu_last_error(void)
 {
-    return g_err;
+    return gcn10::g_err;
 }
 
 int gcn10_gpu_device_count(void)

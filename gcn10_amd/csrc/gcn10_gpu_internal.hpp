@@ -1,0 +1,53 @@
+// gcn10_gpu_internal.hpp -- shared by the translation units of libgcn10_gpu.so.
+#ifndef GCN10_GPU_INTERNAL_HPP
+#define GCN10_GPU_INTERNAL_HPP
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "gcn10_gpu.h"
+
+namespace gcn10 {
+
+// error plumbing: message of the calling thread (gcn10_gpu_last_error)
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return gcn10::fail(e_ == hipErrorOutOfMemory ? GCN10_E_NOMEM : GCN10_E_HIP, \
+                               "%s: %s", #expr, hipGetErrorString(e_));                 \
+    } while (0)
+
+int use_device(gcn10_gpu_ctx *ctx);
+hipStream_t as_stream(gcn10_gpu_ctx *ctx, gcn10_stream_t s);
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+}  // namespace gcn10
+
+struct gcn10_gpu_ctx {
+    int device = -1;
+    int n_cus = 0;
+    hipStream_t main_stream = nullptr;
+    uint8_t *d_lut16 = nullptr;     // kLut16Bytes
+    uint8_t *d_lut1 = nullptr;      // 9 * kLut1Bytes
+    int n_tables = 0;
+    uint8_t *d_hx = nullptr;
+    size_t hx_capacity = 0;
+    uint32_t hx_stride = 0;
+    uint32_t hx_W = 0;
+    uint32_t hx_rows = 0;
+    const char *last_kernel = "";
+    // tuning knobs (gcn10_gpu_set_option); defaults = the round-1 measured best
+    int grid_blocks_per_cu = 8;
+    int ilp16 = 2;          // sub-chunks per loop trip, all-tables kernel (1, 2)
+    int ilp1 = 2;           // same, single-table kernel (1, 2, 4)
+    int nontemporal = 1;
+    int xcd_slabs = 1;
+    bool deflate_ready = false;     // LDS attribute of the tile encoder set on this device
+};
+
+#endif

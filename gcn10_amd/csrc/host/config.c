@@ -44,6 +44,7 @@ int gcn10_config_parse(const char *path, gcn10_config *cfg, char *err, size_t er
     FILE *f;
 
     memset(cfg, 0, sizeof *cfg);
+    cfg->gpu_deflate = 1;
     f = fopen(path, "r");
     if (!f) {
         snprintf(err, errcap, "cannot open config '%s'", path);     /* src/config.c:52 */
@@ -83,6 +84,8 @@ int gcn10_config_parse(const char *path, gcn10_config *cfg, char *err, size_t er
             cfg->io_threads = atoi(val);
         else if (!strcmp(key, "deflate_level"))
             cfg->deflate_level = atoi(val);
+        else if (!strcmp(key, "gpu_deflate"))
+            cfg->gpu_deflate = atoi(val) != 0;
         if (rc != 0) {
             fclose(f);
             snprintf(err, errcap, "malloc failed for %s", key);     /* src/config.c:71 */

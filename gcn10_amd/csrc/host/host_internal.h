@@ -45,6 +45,9 @@ struct gcn10_gpu_api {
                         gcn10_stream_t);
     int (*cn_strip)(gcn10_gpu_ctx *, const uint8_t *, int, int, const int32_t *, unsigned, unsigned,
                     uint8_t *const[GCN10_N_RASTERS], gcn10_stream_t);
+    size_t (*deflate_arena_bound)(int, int, int);
+    int (*deflate_strip)(gcn10_gpu_ctx *, const uint8_t *const *, int, int, int, uint8_t *, size_t,
+                         uint32_t *, unsigned long long *, gcn10_stream_t);
 };
 const struct gcn10_gpu_api *gcn10_gpu_api_get(char *err, size_t errcap);
 

@@ -44,13 +44,20 @@ struct strip_buf {
     uint8_t *d_esa;
     uint8_t *h_out[GCN10_N_RASTERS];        /* pinned */
     uint8_t *d_out[GCN10_N_RASTERS];
-    gcn10_event_t ev_h2d, ev_kernel, ev_d2h;
+    gcn10_event_t ev_h2d, ev_kernel, ev_d2h, ev_meta;
+    /* GPU-side DEFLATE: compressed tiles of all 18 rasters of the strip */
+    uint8_t *d_arena, *h_arena;             /* h_arena pinned */
+    size_t arena_cap;
+    uint32_t *d_table, *h_table;            /* [18][tiles][2]; h_table pinned */
+    unsigned long long *d_cursor, *h_cursor;
+    const uint8_t **d_ptrs;                 /* device array of the 18 d_out pointers */
     /* compression jobs of the strip currently held by this buffer */
     pthread_mutex_t mu;
     pthread_cond_t cv;
     int pending;
     bool d2h_issued;
     int y0, rows;                           /* strip held */
+    struct worker *owner;
 };
 
 struct worker {
@@ -71,6 +78,7 @@ struct worker {
     atomic_bool failed;                     /* a sink job of the current block failed */
     int blocks_done;
     double busy_seconds;
+    double t_read, t_gpu_wait, t_sink_wait, t_setup;   /* where the worker thread's time goes */
 };
 
 struct run {
@@ -89,6 +97,7 @@ struct run {
     int strip_rows;
     int deflate_level;
     bool null_sink;                         /* GCN10_SINK=null: no compression, no files */
+    bool gpu_deflate;                       /* tiles are encoded on the GPU */
     int n_devices;                          /* visible GPUs; worker i uses device i % n_devices */
     int outer_rank, outer_size;             /* this process among the processes of an mpirun / srun */
 };
@@ -155,23 +164,110 @@ static void tile_row_job(void *arg)
     free(j);
 }
 
+/* GPU-deflate sink: append the already compressed tiles of one raster */
+struct put_job {
+    struct worker *w;
+    struct strip_buf *b;
+    gcn10_tiff_writer *tif;
+    int raster, ty0, across, down;          /* tile rows ty0 .. ty0+down of the raster */
+};
+
+static void put_tiles_job(void *arg)
+{
+    struct put_job *j = arg;
+    const uint32_t *tab = j->b->h_table + (size_t)j->raster * (size_t)j->across * (size_t)j->down * 2;
+
+    for (int ty = 0; ty < j->down; ty++) {
+        for (int tx = 0; tx < j->across; tx++) {
+            const uint32_t off = tab[((size_t)ty * j->across + tx) * 2];
+            const uint32_t size = tab[((size_t)ty * j->across + tx) * 2 + 1];
+
+            if (off == 0xffffffffu || size == 0 || (size_t)off + size > j->b->arena_cap ||
+                gcn10_tiff_put_tile(j->tif, tx, j->ty0 + ty, j->b->h_arena + off, size) != 0) {
+                atomic_store(&j->w->failed, true);
+                goto done;
+            }
+        }
+    }
+done:
+    pthread_mutex_lock(&j->b->mu);
+    if (--j->b->pending == 0)
+        pthread_cond_broadcast(&j->b->cv);
+    pthread_mutex_unlock(&j->b->mu);
+    free(j);
+}
+
 static void wait_sink(struct strip_buf *b)
 {
+    double t0 = now_seconds();
+
     pthread_mutex_lock(&b->mu);
     while (b->pending > 0)
         pthread_cond_wait(&b->cv, &b->mu);
     pthread_mutex_unlock(&b->mu);
+    if (b->owner)
+        b->owner->t_sink_wait += now_seconds() - t0;
 }
 
 /* hands the finished strip in buffer b to the compression pool */
+static int drain_strip_inner(struct worker *w, struct strip_buf *b, gcn10_tiff_writer *tifs[GCN10_N_RASTERS],
+                             int W, int H);
+
 static int drain_strip(struct worker *w, struct strip_buf *b, gcn10_tiff_writer *tifs[GCN10_N_RASTERS],
                        int W, int H)
+{
+    double t0 = now_seconds();
+    int rc = drain_strip_inner(w, b, tifs, W, H);
+
+    w->t_gpu_wait += now_seconds() - t0;
+    return rc;
+}
+
+static int drain_strip_inner(struct worker *w, struct strip_buf *b, gcn10_tiff_writer *tifs[GCN10_N_RASTERS],
+                             int W, int H)
 {
     struct run *r = w->run;
 
     if (!b->d2h_issued)
         return 0;
     b->d2h_issued = false;
+    if (r->gpu_deflate) {
+        /* the sizes are known only now: fetch exactly the bytes the encoder produced */
+        const struct gcn10_gpu_api *g = r->gpu;
+        int across = (W + TILE - 1) / TILE, down = (b->rows + TILE - 1) / TILE;
+        size_t used;
+
+        if (g->event_sync(w->ctx, b->ev_meta) != 0)
+            goto gpu_error;
+        used = (size_t)*b->h_cursor;
+        if (used > b->arena_cap) {
+            wlog(w, "ERROR", true, "gpu deflate arena overflow (%zu > %zu)", used, b->arena_cap);
+            return -1;
+        }
+        if (r->null_sink)
+            return 0;
+        if (g->memcpy_d2h(w->ctx, b->h_arena, b->d_arena, used, w->s_d2h) != 0 ||
+            g->event_record(w->ctx, b->ev_d2h, w->s_d2h) != 0 || g->event_sync(w->ctx, b->ev_d2h) != 0)
+            goto gpu_error;
+        for (int k = 0; k < GCN10_N_RASTERS; k++) {
+            struct put_job *j = malloc(sizeof *j);
+
+            if (!j) {
+                wlog(w, "ERROR", true, "malloc failed for tile job");
+                return -1;
+            }
+            *j = (struct put_job){ w, b, tifs[k], k, b->y0 / TILE, across, down };
+            pthread_mutex_lock(&b->mu);
+            b->pending++;
+            pthread_mutex_unlock(&b->mu);
+            gcn10_pool_submit(r->pool, put_tiles_job, j);
+        }
+        (void)H;
+        return 0;
+gpu_error:
+        wlog(w, "ERROR", true, "gpu: %s", g->last_error());
+        return -1;
+    }
     if (r->gpu->event_sync(w->ctx, b->ev_d2h) != 0) {
         wlog(w, "ERROR", true, "gpu: %s", r->gpu->last_error());
         return -1;
@@ -222,6 +318,17 @@ static void free_strip_buffers(struct worker *w)
             if (b->d_out[k]) g->free(w->ctx, b->d_out[k]);
             b->h_out[k] = b->d_out[k] = NULL;
         }
+        if (b->h_arena) g->host_free(w->ctx, b->h_arena);
+        if (b->d_arena) g->free(w->ctx, b->d_arena);
+        if (b->h_table) g->host_free(w->ctx, b->h_table);
+        if (b->d_table) g->free(w->ctx, b->d_table);
+        if (b->h_cursor) g->host_free(w->ctx, b->h_cursor);
+        if (b->d_cursor) g->free(w->ctx, b->d_cursor);
+        if (b->d_ptrs) g->free(w->ctx, (void *)b->d_ptrs);
+        b->h_arena = b->d_arena = NULL;
+        b->h_table = b->d_table = NULL;
+        b->h_cursor = b->d_cursor = NULL;
+        b->d_ptrs = NULL;
         b->h_esa = b->d_esa = NULL;
     }
     w->buf_px = 0;
@@ -242,8 +349,24 @@ static int ensure_strip_buffers(struct worker *w, int W)
         GPU_TRY(w, g->host_alloc(w->ctx, px, (void **)&b->h_esa));
         GPU_TRY(w, g->malloc(w->ctx, px, (void **)&b->d_esa));
         for (int k = 0; k < GCN10_N_RASTERS; k++) {
-            GPU_TRY(w, g->host_alloc(w->ctx, px, (void **)&b->h_out[k]));
+            if (!w->run->gpu_deflate)
+                GPU_TRY(w, g->host_alloc(w->ctx, px, (void **)&b->h_out[k]));
             GPU_TRY(w, g->malloc(w->ctx, px, (void **)&b->d_out[k]));
+        }
+        if (w->run->gpu_deflate) {
+            size_t tiles = (size_t)((W + TILE - 1) / TILE) * (size_t)(w->run->strip_rows / TILE);
+
+            b->arena_cap = g->deflate_arena_bound(W, w->run->strip_rows, GCN10_N_RASTERS);
+            GPU_TRY(w, g->malloc(w->ctx, b->arena_cap, (void **)&b->d_arena));
+            GPU_TRY(w, g->host_alloc(w->ctx, b->arena_cap, (void **)&b->h_arena));
+            GPU_TRY(w, g->malloc(w->ctx, tiles * GCN10_N_RASTERS * 8, (void **)&b->d_table));
+            GPU_TRY(w, g->host_alloc(w->ctx, tiles * GCN10_N_RASTERS * 8, (void **)&b->h_table));
+            GPU_TRY(w, g->malloc(w->ctx, 8, (void **)&b->d_cursor));
+            GPU_TRY(w, g->host_alloc(w->ctx, 8, (void **)&b->h_cursor));
+            GPU_TRY(w, g->malloc(w->ctx, GCN10_N_RASTERS * sizeof(void *), (void **)&b->d_ptrs));
+            GPU_TRY(w, g->memcpy_h2d(w->ctx, (void *)b->d_ptrs, b->d_out, GCN10_N_RASTERS * sizeof(void *),
+                                     w->s_kernel));
+            GPU_TRY(w, g->stream_sync(w->ctx, w->s_kernel));
         }
     }
     w->buf_px = px;
@@ -405,7 +528,11 @@ static int process_block(struct worker *w, int block_id)
 
         /* landcover rows straight into the pinned strip (replaces the malloc +
          * GDALRasterIO of src/raster.c:169-178) */
-        if (gcn10_raster_read(w->esa, xoff, yoff + y0, W, rows, b->h_esa, err, sizeof err) != 0) {
+        double t_r0 = now_seconds();
+        int read_rc = gcn10_raster_read(w->esa, xoff, yoff + y0, W, rows, b->h_esa, err, sizeof err);
+
+        w->t_read += now_seconds() - t_r0;
+        if (read_rc != 0) {
             wlog(w, "ERROR", true, "%s", err);
             wlog(w, "ERROR", true, "esa load failed for block %d", block_id);
             goto out;
@@ -421,11 +548,28 @@ static int process_block(struct worker *w, int block_id)
             g->event_record(w->ctx, b->ev_kernel, w->s_kernel) != 0 ||
             g->stream_wait_event(w->ctx, w->s_d2h, b->ev_kernel) != 0)
             goto gpu_fail;
-        for (int k = 0; k < GCN10_N_RASTERS; k++)
-            if (g->memcpy_d2h(w->ctx, b->h_out[k], b->d_out[k], px, w->s_d2h) != 0)
+        if (r->gpu_deflate) {
+            /* encode the 18 strips where they are; only sizes, offsets and (later, in
+             * drain_strip) the compressed bytes go to the host */
+            int across = (W + TILE - 1) / TILE, down = (rows + TILE - 1) / TILE;
+
+            if (g->deflate_strip(w->ctx, b->d_ptrs, GCN10_N_RASTERS, W, rows, b->d_arena, b->arena_cap,
+                                 b->d_table, b->d_cursor, w->s_kernel) != 0 ||
+                g->event_record(w->ctx, b->ev_kernel, w->s_kernel) != 0 ||
+                g->stream_wait_event(w->ctx, w->s_d2h, b->ev_kernel) != 0 ||
+                g->memcpy_d2h(w->ctx, b->h_cursor, b->d_cursor, 8, w->s_d2h) != 0 ||
+                g->memcpy_d2h(w->ctx, b->h_table, b->d_table,
+                              (size_t)across * down * GCN10_N_RASTERS * 8, w->s_d2h) != 0 ||
+                g->event_record(w->ctx, b->ev_meta, w->s_d2h) != 0)
                 goto gpu_fail;
-        if (g->event_record(w->ctx, b->ev_d2h, w->s_d2h) != 0)
-            goto gpu_fail;
+        }
+        else {
+            for (int k = 0; k < GCN10_N_RASTERS; k++)
+                if (g->memcpy_d2h(w->ctx, b->h_out[k], b->d_out[k], px, w->s_d2h) != 0)
+                    goto gpu_fail;
+            if (g->event_record(w->ctx, b->ev_d2h, w->s_d2h) != 0)
+                goto gpu_fail;
+        }
         b->d2h_issued = true;
         b->y0 = y0;
         b->rows = rows;
@@ -454,7 +598,7 @@ out:
     /* nothing of this block may still be in flight when its buffers are reused */
     for (int i = 0; i < NBUF; i++) {
         if (w->buf[i].d2h_issued) {
-            g->event_sync(w->ctx, w->buf[i].ev_d2h);
+            g->event_sync(w->ctx, r->gpu_deflate ? w->buf[i].ev_meta : w->buf[i].ev_d2h);
             w->buf[i].d2h_issued = false;
         }
         wait_sink(&w->buf[i]);
@@ -511,6 +655,7 @@ static void worker_teardown(struct worker *w)
             if (b->ev_h2d) g->event_destroy(w->ctx, b->ev_h2d);
             if (b->ev_kernel) g->event_destroy(w->ctx, b->ev_kernel);
             if (b->ev_d2h) g->event_destroy(w->ctx, b->ev_d2h);
+            if (b->ev_meta) g->event_destroy(w->ctx, b->ev_meta);
         }
         if (w->d_coarse) g->free(w->ctx, w->d_coarse);
         if (w->d_ci) g->free(w->ctx, w->d_ci);
@@ -539,6 +684,7 @@ static int worker_setup(struct worker *w)
     for (int i = 0; i < NBUF; i++) {
         pthread_mutex_init(&w->buf[i].mu, NULL);
         pthread_cond_init(&w->buf[i].cv, NULL);
+        w->buf[i].owner = w;
     }
     if (g->init(w->index % r->n_devices, &w->ctx) != 0) {
         wlog(w, "ERROR", true, "gpu %d: %s", w->index % r->n_devices, g->last_error());
@@ -552,6 +698,7 @@ static int worker_setup(struct worker *w)
         GPU_TRY(w, g->event_create(w->ctx, &w->buf[i].ev_h2d));
         GPU_TRY(w, g->event_create(w->ctx, &w->buf[i].ev_kernel));
         GPU_TRY(w, g->event_create(w->ctx, &w->buf[i].ev_d2h));
+        GPU_TRY(w, g->event_create(w->ctx, &w->buf[i].ev_meta));
     }
     /* the reference reopens both rasters for every block (src/raster.c:119);
      * here each worker keeps its own handles */
@@ -668,6 +815,7 @@ int gcn10_run(const gcn10_run_options *opt)
     r->strip_rows = r->cfg.strip_rows > 0 ? r->cfg.strip_rows : DEFAULT_STRIP_ROWS;
     r->strip_rows = (r->strip_rows + TILE - 1) / TILE * TILE;
     r->deflate_level = r->cfg.deflate_level;
+    r->gpu_deflate = r->cfg.gpu_deflate != 0;
 
     /* GPUs: one worker ("rank") each */
     r->gpu = gcn10_gpu_api_get(err, sizeof err);
@@ -819,11 +967,19 @@ int gcn10_run(const gcn10_run_options *opt)
     gcn10_log_message(log0, "INFO", msg, true);
     {
         int done_blocks = 0;
+        double busy = 0, rd = 0, gw = 0, sw = 0;
 
-        for (int i = 0; i < r->n_workers; i++)
+        for (int i = 0; i < r->n_workers; i++) {
             done_blocks += r->workers[i].blocks_done;
-        snprintf(msg, sizeof msg, "timing: %d blocks, %.3f s wall, %d gpu worker(s)%s", done_blocks,
-                 now_seconds() - t_start, r->n_workers, r->null_sink ? ", null sink" : "");
+            busy += r->workers[i].busy_seconds;
+            rd += r->workers[i].t_read;
+            gw += r->workers[i].t_gpu_wait;
+            sw += r->workers[i].t_sink_wait;
+        }
+        snprintf(msg, sizeof msg, "timing: %d blocks, %.3f s wall, %d gpu worker(s)%s%s; worker seconds: "
+                 "in blocks %.3f, reading landcover %.3f, waiting for gpu %.3f, waiting for sink %.3f",
+                 done_blocks, now_seconds() - t_start, r->n_workers, r->null_sink ? ", null sink" : "",
+                 r->gpu_deflate ? ", gpu deflate" : ", host zlib", busy, rd, gw, sw);
         gcn10_log_message(log0, "INFO", msg, false);
     }
     exit_code = atomic_load(&r->fatal) ? 1 : 0;

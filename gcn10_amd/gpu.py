@@ -38,6 +38,7 @@ ABI_SYMBOLS = (
     "gcn10_gpu_set_tables", "gcn10_gpu_resample", "gcn10_gpu_modify_hysogs_data",
     "gcn10_gpu_calculate_cn", "gcn10_gpu_prepare_tile", "gcn10_gpu_cn_strip",
     "gcn10_gpu_strip_algorithmic_bytes", "gcn10_gpu_last_kernel_name", "gcn10_gpu_set_option",
+    "gcn10_gpu_deflate_arena_bound", "gcn10_gpu_deflate_strip",
 )
 
 
@@ -89,6 +90,8 @@ def lib():
             "gcn10_gpu_strip_algorithmic_bytes": (sz, [i, i, i, i, u, u]),
             "gcn10_gpu_last_kernel_name": (C.c_char_p, [vp]),
             "gcn10_gpu_set_option": (i, [vp, C.c_char_p, i]),
+            "gcn10_gpu_deflate_arena_bound": (sz, [i, i, i]),
+            "gcn10_gpu_deflate_strip": (i, [vp, vp, i, i, i, vp, sz, vp, vp, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -283,6 +286,30 @@ class Engine:
             arr[r] = outs[r] if r < len(outs) and outs[r] else None
         self._chk(lib().gcn10_gpu_cn_strip(self._ctx, esa_d, W, rows, cj_d, cond_mask, table_mask,
                                            arr, stream), "gcn10_gpu_cn_strip")
+
+    # -- output encode (src/raster.c:204-219 on the GPU) ----------------------
+    def deflate_rasters(self, raster_ptrs: Sequence[int], W: int, rows: int, stream=None):
+        """zlib-encodes every 256x256 tile of the given device rasters.
+
+        Returns (arena bytes as uint8 array, table uint32[n, down, across, 2])."""
+        n = len(raster_ptrs)
+        across, down = (W + 255) // 256, (rows + 255) // 256
+        cap = int(lib().gcn10_gpu_deflate_arena_bound(W, rows, n))
+        ptrs = self.upload(np.array(raster_ptrs, dtype=np.uint64))
+        arena = self.alloc(cap)
+        table = self.alloc(n * across * down * 8)
+        cursor = self.alloc(8)
+        try:
+            self._chk(lib().gcn10_gpu_deflate_strip(self._ctx, ptrs.ptr, n, W, rows, arena.ptr, cap,
+                                                    table.ptr, cursor.ptr, stream),
+                      "gcn10_gpu_deflate_strip")
+            used = int(self.download(cursor.ptr, (1,), dtype=np.uint64, stream=stream)[0])
+            tab = self.download(table.ptr, (n, down, across, 2), dtype=np.uint32, stream=stream)
+            data = self.download(arena.ptr, (min(used, cap),), stream=stream)
+        finally:
+            for b in (ptrs, arena, table, cursor):
+                b.close()
+        return data, tab, used
 
     # -- block level: src/cn.c:205-290 in memory -----------------------------
     def process_block_mem(self, esa: np.ndarray, gt, coarse: np.ndarray, soil_gt,

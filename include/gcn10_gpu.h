@@ -167,6 +167,22 @@ int gcn10_gpu_cn_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, int rows,
 size_t gcn10_gpu_strip_algorithmic_bytes(int W, int rows, int hsx, int hsy,
                                          unsigned cond_mask, unsigned table_mask);
 
+/* ---- output encode: the DEFLATE of save_raster(), on the GPU --------------- */
+/* Replaces the zlib work inside save_raster()'s GDALRasterIO (src/raster.c:204-219:
+ * GTiff, COMPRESS=DEFLATE, TILED=YES, i.e. one zlib stream per 256x256 block).
+ * Every 256x256 tile of `n_rasters` device raster strips (W x rows each, row
+ * major; edge tiles zero padded) becomes one complete zlib stream (RFC 1950/1951,
+ * dynamic Huffman) in `arena_dev`; table_dev[(r*tiles + ty*across + tx)*2 + {0,1}]
+ * receives the stream's byte offset in the arena and its size (offset 0xffffffff:
+ * the arena was too small); *cursor_dev receives the number of arena bytes used.
+ * rasters_dev is a DEVICE array of n_rasters device pointers.  Asynchronous on
+ * `stream`.  The raw rasters never have to cross PCIe. */
+size_t gcn10_gpu_deflate_arena_bound(int W, int rows, int n_rasters);
+int gcn10_gpu_deflate_strip(gcn10_gpu_ctx *ctx, const uint8_t *const *rasters_dev,
+                            int n_rasters, int W, int rows, uint8_t *arena_dev,
+                            size_t arena_cap, uint32_t *table_dev,
+                            unsigned long long *cursor_dev, gcn10_stream_t stream);
+
 /* Launch-shape knobs of the strip kernels, for tuning runs; results never
  * depend on them.  Names: "grid_blocks_per_cu" (1..64), "ilp16" (1|2),
  * "ilp1" (1|2|4), "nontemporal" (0|1), "xcd_slabs" (0|1). */

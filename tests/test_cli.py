@@ -24,7 +24,7 @@ BLOCKS = [(101, 10.0, 49.0, 11.0, 50.0),     # inside
           (104, 20.0, 20.0, 21.0, 21.0)]     # outside the rasters: "invalid raster bounds"
 
 
-def _world(tmp_path, seed=5):
+def _world(tmp_path, seed=5, extra_cfg=""):
     rng = np.random.default_rng(seed)
     small = rng.choice(ESA_NASTY, size=(2000 // 20, 3000 // 20))
     esa = np.repeat(np.repeat(small, 20, axis=0), 20, axis=1)
@@ -36,8 +36,9 @@ def _world(tmp_path, seed=5):
     tiffutil.write_block_shapefile(str(tmp_path / "blocks"), BLOCKS)
     (tmp_path / "config.txt").write_text(
         "# test config\nhysogs_data_path=%s\nesa_data_path=%s\nblocks_shp_path=%s\n"
-        "lookup_table_path=%s\nlog_dir=%s\nstrip_rows=256\nio_threads=4\n"
-        % (tmp_path / "soil_lzw.tif", tmp_path / "esa.tif", tmp_path / "blocks.shp", LOOKUPS, tmp_path / "logs"))
+        "lookup_table_path=%s\nlog_dir=%s\nstrip_rows=256\nio_threads=4\n%s"
+        % (tmp_path / "soil_lzw.tif", tmp_path / "esa.tif", tmp_path / "blocks.shp", LOOKUPS, tmp_path / "logs",
+           extra_cfg))
     return esa, soil
 
 
@@ -77,8 +78,9 @@ def test_no_gpu_means_no_run(tmp_path):
 
 
 @pytest.mark.gpu
-def test_blocks_equal_oracle_and_reference_conventions(tmp_path, tables):
-    esa, soil = _world(tmp_path)
+@pytest.mark.parametrize("gpu_deflate", [1, 0], ids=["gpu-deflate", "host-zlib"])
+def test_blocks_equal_oracle_and_reference_conventions(tmp_path, tables, gpu_deflate):
+    esa, soil = _world(tmp_path, extra_cfg="gpu_deflate=%d\n" % gpu_deflate)
     (tmp_path / "ids.txt").write_text("101 102\n103\n104 999\n")
     out = _run(tmp_path, "-c", "config.txt", "-l", "ids.txt")
     assert out.returncode == 0, out.stderr[-2000:]

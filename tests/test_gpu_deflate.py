@@ -1,0 +1,95 @@
+"""GPU tile DEFLATE (include/gcn10_gpu.h, gcn10_gpu_deflate_strip): every stream must inflate,
+with stock zlib, to exactly the 256x256 tile (zero padded at raster edges) it encodes."""
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CN_VALUES = np.array([0, 15, 30, 35, 41, 48, 51, 55, 59, 62, 68, 72, 77, 83, 98, 255], dtype=np.uint8)
+
+
+def _rasters(kind, H, W, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":
+        return np.full((H, W), 255, np.uint8)
+    if kind == "zeros":
+        return np.zeros((H, W), np.uint8)
+    if kind == "patches":           # 25-px soil cells x landcover patches, like a CN raster
+        a = rng.choice(CN_VALUES, size=((H + 24) // 25, (W + 24) // 25))
+        return np.repeat(np.repeat(a, 25, axis=0), 25, axis=1)[:H, :W].copy()
+    if kind == "noisy":             # i.i.d. over the CN value set: ~4 bits/px of entropy
+        return rng.choice(CN_VALUES, size=(H, W)).astype(np.uint8)
+    if kind == "random":            # incompressible: the stored-block fallback
+        return rng.integers(0, 256, size=(H, W), dtype=np.uint8)
+    if kind == "rows":              # every row repeats the one above (distance-256 matches only)
+        return np.repeat(rng.integers(0, 256, size=(1, W), dtype=np.uint8), H, axis=0)
+    if kind == "skewed":            # one dominant symbol + rare ones: deep Huffman trees
+        v = np.full((H, W), 77, np.uint8)
+        idx = rng.random((H, W))
+        for k, thr in enumerate([1e-1, 3e-2, 1e-2, 3e-3, 1e-3, 3e-4, 1e-4, 5e-5, 2e-5]):
+            v[idx < thr] = k
+        return v
+    raise ValueError(kind)
+
+
+def _check(engine, rasters, W, H):
+    bufs = [engine.upload(r) for r in rasters]
+    data, table, used = engine.deflate_rasters([b.ptr for b in bufs], W, H)
+    for b in bufs:
+        b.close()
+    across, down = (W + 255) // 256, (H + 255) // 256
+    assert table.shape == (len(rasters), down, across, 2)
+    total = 0
+    for r, img in enumerate(rasters):
+        for ty in range(down):
+            for tx in range(across):
+                off, size = int(table[r, ty, tx, 0]), int(table[r, ty, tx, 1])
+                assert off != 0xFFFFFFFF and 0 < size <= 65552 and off % 16 == 0 and off + size <= used
+                want = np.zeros((256, 256), np.uint8)
+                part = img[ty * 256:(ty + 1) * 256, tx * 256:(tx + 1) * 256]
+                want[:part.shape[0], :part.shape[1]] = part
+                got = zlib.decompress(data[off:off + size].tobytes())
+                assert got == want.tobytes(), (r, ty, tx)
+                total += size
+    return total
+
+
+@pytest.mark.parametrize("kind", ["uniform", "zeros", "patches", "noisy", "random", "rows", "skewed"])
+def test_streams_inflate_to_the_tiles(engine, kind):
+    H, W = 512, 768
+    img = _rasters(kind, H, W, 1)
+    size = _check(engine, [img], W, H)
+    ref = sum(len(zlib.compress(img[y:y + 256, x:x + 256].tobytes(), 6))
+              for y in range(0, H, 256) for x in range(0, W, 256))
+    print("%-8s gpu %8d B   zlib-6 %8d B   ratio gpu/zlib %.2f   vs raw %.3f"
+          % (kind, size, ref, size / ref, size / img.size))
+    if kind in ("uniform", "zeros"):
+        assert size < 6 * 300           # a constant tile: 256 one-token rows, ~250 B (266:1)
+    if kind == "random":
+        assert size == 6 * 65552        # stored fallback, never worse than raw + 16 B
+    if kind in ("patches", "noisy", "rows", "skewed"):
+        assert size < 2.0 * ref         # within 2x of zlib level 6 on CN-like data
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (256, 256), (255, 257), (300, 700), (513, 1025), (1000, 36001 // 16)])
+def test_edge_tiles_and_odd_widths(engine, shape):
+    H, W = shape
+    imgs = [_rasters("patches", H, W, 3), _rasters("noisy", H, W, 4), _rasters("uniform", H, W, 5)]
+    _check(engine, imgs, W, H)
+
+
+def test_eighteen_rasters_in_one_launch(engine):
+    H, W = 512, 1040
+    imgs = [_rasters(["patches", "noisy", "skewed"][i % 3], H, W, 10 + i) for i in range(18)]
+    _check(engine, imgs, W, H)
+
+
+def test_argument_errors(engine):
+    from gcn10_amd import gpu
+    with pytest.raises(gpu.Gcn10GpuError):
+        engine.deflate_rasters([], 256, 256)
+    assert gpu.lib().gcn10_gpu_deflate_arena_bound(256, 256, 1) == 65552
+    assert gpu.lib().gcn10_gpu_deflate_arena_bound(257, 256, 2) == 4 * 65552
+    assert gpu.lib().gcn10_gpu_deflate_arena_bound(0, 256, 1) == 0

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--modes", default="null,files")
     ap.add_argument("--pattern", default="patches")
     ap.add_argument("--deflate-level", type=int, default=0)
+    ap.add_argument("--gpu-deflate", type=int, default=1)
     a = ap.parse_args()
     wd = a.workdir
     shutil.rmtree(wd, ignore_errors=True)
@@ -58,11 +59,11 @@ def main():
                                    [(i + 1, 3.0 * i, 0.0, 3.0 * (i + 1), 3.0) for i in range(nb)])
     with open(os.path.join(wd, "config.txt"), "w") as f:
         f.write("hysogs_data_path=%s/soil.tif\nesa_data_path=%s/esa.tif\nblocks_shp_path=%s/blocks.shp\n"
-                "lookup_table_path=%s\nlog_dir=%s/logs\nstrip_rows=%d\ndeflate_level=%d\n"
+                "lookup_table_path=%s\nlog_dir=%s/logs\nstrip_rows=%d\ndeflate_level=%d\ngpu_deflate=%d\n"
                 % (wd, wd, wd, os.path.join(ROOT, "tests", "golden", "lookups"), wd, a.strip_rows,
-                   a.deflate_level))
+                   a.deflate_level, a.gpu_deflate))
     build_s = time.time() - t0
-    res = {"size": size, "blocks": nb, "strip_rows": a.strip_rows, "gpus": a.gpus, "pattern": a.pattern,
+    res = {"size": size, "blocks": nb, "strip_rows": a.strip_rows, "gpus": a.gpus, "pattern": a.pattern, "gpu_deflate": a.gpu_deflate,
            "world_build_seconds": round(build_s, 1), "modes": {}}
     for mode in a.modes.split(","):
         env = dict(os.environ)
@@ -82,7 +83,8 @@ def main():
             p = os.path.join(wd, d)
             if os.path.isdir(p):
                 nbytes += sum(os.path.getsize(os.path.join(p, f)) for f in os.listdir(p))
-        res["modes"][mode] = {"rc": out.returncode, "blocks_done": done, "seconds": round(secs, 3),
+        mt = re.search(r"worker seconds: (.*)", log)
+        res["modes"][mode] = {"rc": out.returncode, "worker_seconds": mt.group(1) if mt else None, "blocks_done": done, "seconds": round(secs, 3),
                               "cn_gpx_per_s": round(done * size * size * 18 / secs / 1e9, 3) if secs else None,
                               "seconds_per_block": round(secs / done, 3) if done else None,
                               "output_bytes": nbytes, "stderr_tail": out.stderr[-300:] if out.returncode else ""}
