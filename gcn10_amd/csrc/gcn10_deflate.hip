@@ -12,19 +12,21 @@
 // the bytes differ from zlib's own output (file bytes are not a parity target,
 // decoded pixels are: tests inflate every tile and compare).
 //
-// Encoder (per 256x256 tile, 256 threads, thread t = tile row t):
+// Encoder, three launches per strip (all tiles of all 18 rasters in each):
 //   matches   only two distances are tried: 1 (run of the previous byte) and 256
 //             (same column, row above) -- the two ways CN rasters repeat (10 m
 //             landcover patches, 250 m soil cells); a match never crosses the end
-//             of its row, so rows parse independently (greedy, min length 3)
-//   pass 1    every row counts its literal/length and distance symbols (LDS atomics)
-//   codes     thread 0 builds the length-limited (15) canonical Huffman code of the
-//             tile's own statistics and writes the dynamic block header; the
-//             code-length alphabet uses a fixed complete code (13 x 4 bit, 6 x 5 bit)
-//   pass 2    rows re-parse and sum their bit lengths; prefix sum gives bit offsets
-//   pass 3    rows re-parse and OR their bits into the LDS output image
-//   trailer   Adler-32 from per-row partial sums; stored-block fallback when the
-//             Huffman stream would exceed the raw size
+//             of its row, so the 256 rows of a tile parse independently (greedy,
+//             minimum length 3).  Candidates are found with byte-compare bit masks,
+//             so literal stretches and run lengths cost a few bit operations
+//   pass A    one workgroup per tile (thread t = row t): symbol statistics, Adler-32
+//   pass B    one THREAD per tile: length-limited (15) canonical Huffman code of the
+//             tile's own statistics + the dynamic block header; the code-length
+//             alphabet uses a fixed complete code (13 x 4 bit, 6 x 5 bit).  Serial
+//             per tile; the ~10^4 tiles of a strip supply the parallelism
+//   pass C    one workgroup per tile: rows re-parse, sum their bit lengths, a prefix
+//             sum places them, rows OR their bits into an LDS image of the stream;
+//             stored-block fallback when Huffman coding would exceed the raw size
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -83,82 +85,182 @@ struct TileJob {
     uint8_t *arena;
     uint32_t *table;                    // [n_rasters][tiles][2] = offset, size
     unsigned long long *cursor;
-    uint32_t W, rows, across, down;
+    uint32_t *hist;                     // [n_tiles][kHistWords]   (pass A -> B)
+    uint8_t *books;                     // [n_tiles][kBookBytes]   (pass B -> C)
+    uint32_t W, rows, across, down, n_tiles;
     unsigned long long arena_cap;
 };
 
-struct Shared {
-    uint8_t tile[kTile * kRowStride];
-    uint32_t out[kOutWords];
-    uint32_t lit_hist[288];
-    uint32_t dist_hist[32];
-    uint16_t lit_code[288];
+// per-tile statistics written by pass A: 288 literal/length counts, 2 distance
+// counts (codes 0 and 15), the tile's Adler-32
+constexpr int kHistWords = 288 + 2 + 2;
+// per-tile code book written by pass B
+struct Book {
     uint8_t lit_len[288];
-    uint16_t dist_code[32];
-    uint8_t dist_len[32];
-    uint32_t row_bits[kTile];
-    uint32_t scan[kTile];
-    unsigned long long adler_a[kTile];
-    unsigned long long adler_b[kTile];
-    // Huffman workspace (thread 0)
-    uint16_t sym[288];
-    uint32_t weight[576];
-    uint16_t parent[576];
-    uint8_t depth[576];
-    uint32_t header_bits;
-    uint32_t total_bits;
-    uint32_t stream_bytes;
-    unsigned long long slot;
-    uint32_t use_stored;
+    uint16_t lit_code[288];
+    uint8_t dist_len[2];        // distance codes 0 (distance 1) and 15 (distance 256)
+    uint8_t pad[2];
+    uint16_t dist_code[2];
+    uint32_t header_bits;       // bit position after the block header (zlib header included)
+    uint32_t header[64];        // the first header_bits bits of the stream
+};
+constexpr int kBookBytes = (int)sizeof(Book);
+
+// ------------------------------------------------------------------------
+// shared by passes A and C: the tile in LDS and the row parser
+// ------------------------------------------------------------------------
+
+// One wave reads one 256-byte tile row per step (coalesced); rows need not be
+// dword aligned (W = 36001 blocks), gfx950 serves unaligned dword loads.  Pixels
+// outside the raster are zero, as GDAL pads edge blocks.
+__device__ __forceinline__ void load_tile(const TileJob &job, const uint8_t *src, uint32_t tx, uint32_t ty,
+                                          uint8_t *tile, int t)
+{
+    typedef uint32_t u32_u __attribute__((aligned(1)));
+    const uint32_t x = tx * kTile + (uint32_t)(t & 63) * 4u;
+    const uint32_t y0 = ty * kTile + (uint32_t)(t >> 6);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(tile) + (t & 63);
+    if ((tx + 1) * kTile <= job.W && (ty + 1) * kTile <= job.rows) {
+        // interior tile: 64 independent loads per thread, issued 16 at a time
+        const uint8_t *p = src + (size_t)y0 * job.W + x;
+        const size_t step = (size_t)job.W * 4;
+#pragma unroll 1
+        for (int i0 = 0; i0 < kTile / 4; i0 += 16) {
+            uint32_t v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                v[i] = *reinterpret_cast<const u32_u *>(p + (size_t)(i0 + i) * step);
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                dst[((i0 + i) * 4 + (t >> 6)) * (kRowStride / 4)] = v[i];
+        }
+        return;
+    }
+    for (int i = 0; i < kTile / 4; i++) {
+        const int r = i * 4 + (t >> 6);
+        const uint32_t y = ty * kTile + (uint32_t)r;
+        uint32_t v = 0;
+        if (y < job.rows && x < job.W) {
+            const uint8_t *p = src + (size_t)y * job.W + x;
+            if (x + 4u <= job.W) {
+                v = *reinterpret_cast<const u32_u *>(p);
+            }
+            else {
+                for (uint32_t k = 0; x + k < job.W; k++)
+                    v |= (uint32_t)p[k] << (8 * k);
+            }
+        }
+        dst[r * (kRowStride / 4)] = v;
+    }
+}
+
+// 4 flag bits of a dword: bit k set iff byte k of d is zero
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t d)
+{
+    const uint32_t m = ~(((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d | 0x7f7f7f7fu);   // 0x80 per zero byte
+    return (((m >> 7) * 0x00204081u) >> 21) & 0xfu;
+}
+
+// The two match candidates of every position of tile row t as bit masks:
+// near bit x: byte x equals the previous byte of the stream (distance 1)
+// far  bit x: byte x equals the byte above it (distance 256)
+struct RowMasks {
+    unsigned long long near_[4], far_[4];
 };
 
-// serial bit writer for the block header (thread 0)
-struct BitWriter {
-    uint32_t *out;
-    uint32_t pos;       // bit position
-    __device__ void put(uint32_t value, int nbits)
-    {
-        if (nbits == 0)
-            return;
-        const uint32_t w = pos >> 5, sh = pos & 31;
-        out[w] |= value << sh;
-        if (sh + nbits > 32)
-            out[w + 1] |= value >> (32 - sh);
-        pos += nbits;
+__device__ __forceinline__ void row_masks(const uint8_t *tile, int t, RowMasks &m)
+{
+    const uint32_t *row = reinterpret_cast<const uint32_t *>(tile + t * kRowStride);
+    const uint32_t *above = reinterpret_cast<const uint32_t *>(tile + (t - 1) * kRowStride);
+    uint32_t prev = t > 0 ? above[63] : 0u;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        unsigned long long nm = 0, fm = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t r = row[q * 16 + j];
+            const uint32_t shifted = (r << 8) | (prev >> 24);
+            nm |= (unsigned long long)zero_bytes(r ^ shifted) << (4 * j);
+            if (t > 0)
+                fm |= (unsigned long long)zero_bytes(r ^ above[q * 16 + j]) << (4 * j);
+            prev = r;
+        }
+        m.near_[q] = nm;
+        m.far_[q] = fm;
     }
-};
+    if (t == 0)
+        m.near_[0] &= ~1ull;        // the tile's first byte has no predecessor
+}
+
+__device__ __forceinline__ unsigned long long pick(const unsigned long long (&m)[4], int w)
+{
+    return w == 0 ? m[0] : w == 1 ? m[1] : w == 2 ? m[2] : m[3];
+}
+
+// number of consecutive set bits starting at bit x (0 <= x < 256)
+__device__ __forceinline__ int run_from(const unsigned long long (&m)[4], int x)
+{
+    int len = 0;
+    for (;;) {
+        const int pos = x + len;
+        if (pos >= kTile)
+            return len;
+        const int b = pos & 63;
+        const unsigned long long inv = ~(pick(m, pos >> 6) >> b);
+        const int n = inv ? __builtin_ctzll(inv) : 64;
+        if (n < 64 - b)
+            return len + n;
+        len += 64 - b;
+    }
+}
+
+// next position >= x where either mask has a set bit (256 if none)
+__device__ __forceinline__ int next_candidate(const RowMasks &m, int x)
+{
+    for (int pos = x; pos < kTile;) {
+        const int b = pos & 63;
+        const unsigned long long v = (pick(m.near_, pos >> 6) | pick(m.far_, pos >> 6)) >> b;
+        if (v)
+            return pos + __builtin_ctzll(v);
+        pos += 64 - b;
+    }
+    return kTile;
+}
 
 // What a row parse does with each token.
 enum { kCount = 0, kMeasure = 1, kEmit = 2 };
+
+struct CodeView {               // the code book as the parser sees it (LDS)
+    const uint8_t *lit_len;
+    const uint16_t *lit_code;
+    uint8_t dist_len[2];
+    uint16_t dist_code[2];
+};
 
 struct RowEmitter {
     uint32_t *out;
     uint32_t pos;
     unsigned long long acc;
     int nacc;
-    __device__ void put(uint32_t value, int nbits)
+    __device__ __forceinline__ void put(uint32_t value, int nbits)
     {
         acc |= (unsigned long long)value << nacc;
         nacc += nbits;
-        while (nacc >= 32) {
-            flush32();
+        if (nacc >= 32) {
+            const uint32_t lo = (uint32_t)acc;
+            const uint32_t w = pos >> 5, sh = pos & 31;
+            atomicOr(&out[w], lo << sh);
+            if (sh)
+                atomicOr(&out[w + 1], lo >> (32 - sh));
+            acc >>= 32;
+            nacc -= 32;
+            pos += 32;
         }
     }
-    __device__ void flush32()
-    {
-        const uint32_t lo = (uint32_t)acc;
-        const uint32_t w = pos >> 5, sh = pos & 31;
-        atomicOr(&out[w], lo << sh);
-        if (sh)
-            atomicOr(&out[w + 1], lo >> (32 - sh));
-        acc >>= 32;
-        nacc -= 32;
-        pos += 32;
-    }
-    __device__ void finish()
+    __device__ __forceinline__ void finish()
     {
         if (nacc > 0) {
-            const uint32_t lo = (uint32_t)acc & ((nacc >= 32) ? 0xffffffffu : ((1u << nacc) - 1u));
+            const uint32_t lo = (uint32_t)acc & (0xffffffffu >> (32 - nacc));
             const uint32_t w = pos >> 5, sh = pos & 31;
             atomicOr(&out[w], lo << sh);
             if (sh && sh + nacc > 32)
@@ -170,314 +272,455 @@ struct RowEmitter {
     }
 };
 
-// Greedy parse of tile row t.  MODE selects what happens per token.
+// Greedy parse of tile row t (matches of length >= 3 at distance 1 or 256, never
+// crossing the row's end).  Literal stretches are skipped with the masks; only
+// the literal bytes themselves are read from LDS.
 template <int MODE>
-__device__ __forceinline__ uint32_t parse_row(Shared &sh, int t, RowEmitter *em)
+__device__ __forceinline__ uint32_t parse_row(const uint8_t *tile, int t, const RowMasks &m,
+                                              uint32_t *lit_hist, uint32_t *dist_hist,
+                                              const CodeView *cv, RowEmitter *em)
 {
-    const uint8_t *row = sh.tile + t * kRowStride;
-    const uint8_t *above = row - kRowStride;        // valid for t > 0
+    const uint8_t *row = tile + t * kRowStride;
     uint32_t bits = 0;
     int x = 0;
 
     while (x < kTile) {
-        const int room = kTile - x;                 // a match stays inside the row
-        int l1 = 0, l256 = 0;
-        // distance 1: previous byte of the stream (last byte of the row above for x = 0)
-        if (x > 0 || t > 0) {
-            const uint8_t prev = x > 0 ? row[x - 1] : above[kTile - 1];
-            if (row[x] == prev) {
-                l1 = 1;
-                while (l1 < room && row[x + l1] == prev)
-                    l1++;
-            }
+        const int cand = next_candidate(m, x);
+        // literals up to the next position where a match could start
+        for (; x < cand; x++) {
+            const int s = row[x];
+            if (MODE == kCount)
+                atomicAdd(&lit_hist[s], 1u);
+            else if (MODE == kMeasure)
+                bits += cv->lit_len[s];
+            else
+                em->put(cv->lit_code[s], cv->lit_len[s]);
         }
-        if (t > 0 && row[x] == above[x]) {
-            l256 = 1;
-            while (l256 < room && row[x + l256] == above[x + l256])
-                l256++;
-        }
-        int len = l1 >= l256 ? l1 : l256;           // tie: distance 1 (no extra bits)
-        const bool far = l256 > l1;
-        if (len > 258)
-            len = 258;
+        if (x >= kTile)
+            break;
+        const int l1 = run_from(m.near_, x);
+        const int l256 = run_from(m.far_, x);
+        const bool far = l256 > l1;                 // tie: distance 1 (no extra bits)
+        const int len = far ? l256 : l1;            // <= 256 - x by construction
         if (len >= 3) {
             const int lc = length_code(len);
             const int ls = 257 + lc;
-            const int ds = far ? 15 : 0;            // distance 256 -> code 15 (193..256, 6 extra bits)
+            const int di = far ? 1 : 0;
             if (MODE == kCount) {
-                atomicAdd(&sh.lit_hist[ls], 1u);
-                atomicAdd(&sh.dist_hist[ds], 1u);
+                atomicAdd(&lit_hist[ls], 1u);
+                atomicAdd(&dist_hist[di], 1u);
             }
             else if (MODE == kMeasure) {
-                bits += sh.lit_len[ls] + kLenExtra[lc] + sh.dist_len[ds] + (far ? 6 : 0);
+                bits += cv->lit_len[ls] + kLenExtra[lc] + cv->dist_len[di] + (far ? 6 : 0);
             }
             else {
-                em->put(sh.lit_code[ls], sh.lit_len[ls]);
+                em->put(cv->lit_code[ls], cv->lit_len[ls]);
                 if (kLenExtra[lc])
-                    em->put((uint32_t)(len - (lc == 28 ? 258 : kLenBase[lc])), kLenExtra[lc]);
-                em->put(sh.dist_code[ds], sh.dist_len[ds]);
+                    em->put((uint32_t)(len - kLenBase[lc]), kLenExtra[lc]);
+                em->put(cv->dist_code[di], cv->dist_len[di]);
                 if (far)
-                    em->put(63u, 6);                // 256 - 193
+                    em->put(63u, 6);                // 256 - 193: distance code 15 has 6 extra bits
             }
             x += len;
         }
         else {
             const int s = row[x];
             if (MODE == kCount)
-                atomicAdd(&sh.lit_hist[s], 1u);
+                atomicAdd(&lit_hist[s], 1u);
             else if (MODE == kMeasure)
-                bits += sh.lit_len[s];
+                bits += cv->lit_len[s];
             else
-                em->put(sh.lit_code[s], sh.lit_len[s]);
+                em->put(cv->lit_code[s], cv->lit_len[s]);
             x++;
         }
     }
     return bits;
 }
 
-// Length-limited canonical Huffman code of hist[0..n) -> len[], code[] (bit-reversed).
-// Thread 0 only.  Two-queue construction on symbols sorted by frequency, then the
-// Kraft fix-up zlib-style encoders use to cap the depth at max_len.
-__device__ void build_code(Shared &sh, const uint32_t *hist, int n, int max_len, uint8_t *len,
-                           uint16_t *code)
-{
-    int m = 0;
-    for (int s = 0; s < n; s++) {
-        len[s] = 0;
-        code[s] = 0;
-        if (hist[s]) {
-            // insertion sort by (frequency, symbol)
-            int i = m++;
-            const uint32_t f = hist[s];
-            while (i > 0 && sh.weight[i - 1] > f) {
-                sh.weight[i] = sh.weight[i - 1];
-                sh.sym[i] = sh.sym[i - 1];
-                i--;
-            }
-            sh.weight[i] = f;
-            sh.sym[i] = (uint16_t)s;
-        }
-    }
-    if (m == 0)
-        return;
-    if (m == 1) {
-        len[sh.sym[0]] = 1;         // a lone symbol still needs one bit
-        return;
-    }
-    // leaves 0..m-1 (sorted), internal nodes m..2m-2 created in non-decreasing weight order
-    int leaf = 0, inode = m, next = m;
-    for (; next < 2 * m - 1; next++) {
-        uint32_t w = 0;
-        for (int k = 0; k < 2; k++) {
-            int pick;
-            if (leaf < m && (inode >= next || sh.weight[leaf] <= sh.weight[inode]))
-                pick = leaf++;
-            else
-                pick = inode++;
-            w += sh.weight[pick];
-            sh.parent[pick] = (uint16_t)next;
-        }
-        sh.weight[next] = w;
-    }
-    // depths from the root down
-    int count[33];
-    for (int i = 0; i <= 32; i++)
-        count[i] = 0;
-    sh.depth[2 * m - 2] = 0;
-    for (int i = 2 * m - 3; i >= 0; i--) {
-        const int d = sh.depth[sh.parent[i]] + 1;
-        sh.depth[i] = (uint8_t)(d > 32 ? 32 : d);
-        if (i < m)
-            count[d > max_len ? max_len : d]++;
-    }
-    // cap at max_len: restore the Kraft equality
-    {
-        unsigned long long total = 0;
-        for (int i = 1; i <= max_len; i++)
-            total += (unsigned long long)count[i] << (max_len - i);
-        while (total > (1ull << max_len)) {
-            count[max_len]--;
-            for (int i = max_len - 1; i > 0; i--) {
-                if (count[i]) {
-                    count[i]--;
-                    count[i + 1] += 2;
-                    break;
-                }
-            }
-            total--;
-        }
-    }
-    // hand the lengths out: most frequent symbols (end of the sorted list) get the shortest
-    {
-        int idx = m - 1;
-        for (int l = 1; l <= max_len; l++)
-            for (int c = 0; c < count[l]; c++)
-                len[sh.sym[idx--]] = (uint8_t)l;
-    }
-    // canonical codes, RFC 1951 3.2.2
-    {
-        uint32_t next_code[17];
-        uint32_t c = 0;
-        int bl[17];
-        for (int i = 0; i <= 16; i++)
-            bl[i] = 0;
-        for (int s = 0; s < n; s++)
-            bl[len[s]]++;
-        bl[0] = 0;
-        for (int l = 1; l <= max_len; l++) {
-            c = (c + (uint32_t)bl[l - 1]) << 1;
-            next_code[l] = c;
-        }
-        for (int s = 0; s < n; s++)
-            if (len[s])
-                code[s] = (uint16_t)bitrev(next_code[len[s]]++, len[s]);
-    }
-}
+// ------------------------------------------------------------------------
+// pass A: symbol statistics + Adler-32, one workgroup per tile
+// ------------------------------------------------------------------------
+struct SharedA {
+    uint8_t tile[kTile * kRowStride];
+    uint32_t lit_hist[288];
+    uint32_t dist_hist[2];
+    uint32_t adler_a[kTile];
+    uint32_t adler_b[kTile];
+};
 
-// dynamic block header: BFINAL, BTYPE, HLIT, HDIST, HCLEN, code-length code, code lengths
-__device__ void write_header(Shared &sh, BitWriter &bw)
-{
-    // canonical fixed code of the code-length alphabet (see kClLen)
-    uint16_t cl_code[19];
-    {
-        uint32_t c4 = 0, c5 = 26;       // 13 four-bit codes, then five-bit codes from 13 << 1
-        for (int s = 0; s < 19; s++)
-            cl_code[s] = (uint16_t)(kClLen[s] == 4 ? bitrev(c4++, 4) : bitrev(c5++, 5));
-    }
-    int hlit = kNumLit;
-    while (hlit > 257 && sh.lit_len[hlit - 1] == 0)
-        hlit--;
-    int hdist = kNumDist;
-    while (hdist > 1 && sh.dist_len[hdist - 1] == 0)
-        hdist--;
-
-    bw.put(1, 1);                       // BFINAL
-    bw.put(2, 2);                       // BTYPE = 10, dynamic Huffman
-    bw.put((uint32_t)(hlit - 257), 5);
-    bw.put((uint32_t)(hdist - 1), 5);
-    bw.put(19 - 4, 4);                  // HCLEN: all 19
-    for (int i = 0; i < 19; i++)
-        bw.put(kClLen[kClOrder[i]], 3);
-
-    // run-length code the hlit + hdist lengths as one sequence (runs may span both)
-    const int total = hlit + hdist;
-    int i = 0;
-    while (i < total) {
-        const int v = i < hlit ? sh.lit_len[i] : sh.dist_len[i - hlit];
-        int run = 1;
-        while (i + run < total) {
-            const int j = i + run;
-            const int vj = j < hlit ? sh.lit_len[j] : sh.dist_len[j - hlit];
-            if (vj != v)
-                break;
-            run++;
-        }
-        if (v == 0) {
-            int left = run;
-            while (left >= 11) {
-                const int r = left > 138 ? 138 : left;
-                bw.put(cl_code[18], kClLen[18]);
-                bw.put((uint32_t)(r - 11), 7);
-                left -= r;
-            }
-            if (left >= 3) {
-                bw.put(cl_code[17], kClLen[17]);
-                bw.put((uint32_t)(left - 3), 3);
-                left = 0;
-            }
-            while (left-- > 0)
-                bw.put(cl_code[0], kClLen[0]);
-        }
-        else {
-            int left = run - 1;
-            bw.put(cl_code[v], kClLen[v]);
-            while (left >= 3) {
-                const int r = left > 6 ? 6 : left;
-                bw.put(cl_code[16], kClLen[16]);
-                bw.put((uint32_t)(r - 3), 2);
-                left -= r;
-            }
-            while (left-- > 0)
-                bw.put(cl_code[v], kClLen[v]);
-        }
-        i += run;
-    }
-}
-
-__global__ __launch_bounds__(kTile) void deflate_tiles_kernel(const TileJob job)
+__global__ __launch_bounds__(kTile) void deflate_stats_kernel(const TileJob job)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    Shared &sh = *reinterpret_cast<Shared *>(smem);
+    SharedA &sh = *reinterpret_cast<SharedA *>(smem);
     const int t = threadIdx.x;
     const uint32_t tiles = job.across * job.down;
     const uint32_t raster = blockIdx.x / tiles;
     const uint32_t tix = blockIdx.x - raster * tiles;
     const uint32_t ty = tix / job.across, tx = tix - ty * job.across;
-    const uint8_t *src = job.rasters[raster];
 
-    // ---- load the tile (zero padded at the raster's right / bottom edge), zero the output.
-    // One wave reads one 256-byte tile row per step (coalesced); rows need not be
-    // dword aligned (W = 36001 blocks), gfx950 serves unaligned dword loads ----
+    load_tile(job, job.rasters[raster], tx, ty, sh.tile, t);
+    for (int i = t; i < 288; i += kTile)
+        sh.lit_hist[i] = 0;
+    if (t < 2)
+        sh.dist_hist[t] = 0;
+    __syncthreads();
+
+    // Adler-32 partial sums of row t: A = sum x, B = sum (n - i) x_i over the row,
+    // n = 65536, i = 256 t + k the byte's position in the tile
     {
-        const uint32_t x = tx * kTile + (uint32_t)(t & 63) * 4u;
-        for (int i = 0; i < kTile / 4; i++) {
-            const int r = i * 4 + (t >> 6);
-            const uint32_t y = ty * kTile + (uint32_t)r;
-            uint32_t v = 0;
-            if (y < job.rows && x < job.W) {
-                const uint8_t *p = src + (size_t)y * job.W + x;
-                if (x + 4u <= job.W) {
-                    typedef uint32_t u32_u __attribute__((aligned(1)));
-                    v = *reinterpret_cast<const u32_u *>(p);
-                }
-                else {
-                    for (uint32_t k = 0; x + k < job.W; k++)
-                        v |= (uint32_t)p[k] << (8 * k);
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(sh.tile + t * kRowStride);
+        uint32_t a = 0, b = 0;
+#pragma unroll 8
+        for (int j = 0; j < kTile / 4; j++) {
+            const uint32_t v = row[j];
+            const uint32_t b0 = v & 0xff, b1 = (v >> 8) & 0xff, b2 = (v >> 16) & 0xff, b3 = v >> 24;
+            a += b0 + b1 + b2 + b3;
+            b += (uint32_t)(kTile - 4 * j) * b0 + (uint32_t)(kTile - 4 * j - 1) * b1 +
+                 (uint32_t)(kTile - 4 * j - 2) * b2 + (uint32_t)(kTile - 4 * j - 3) * b3;
+        }
+        sh.adler_a[t] = a;      // <= 256 * 255
+        sh.adler_b[t] = (uint32_t)(((unsigned long long)b +
+                                    (unsigned long long)(kTileBytes - kTile * (t + 1)) * a) % 65521ull);
+    }
+
+    RowMasks m;
+    row_masks(sh.tile, t, m);
+    parse_row<kCount>(sh.tile, t, m, sh.lit_hist, sh.dist_hist, nullptr, nullptr);
+    __syncthreads();
+
+    uint32_t *out = job.hist + (size_t)blockIdx.x * kHistWords;
+    for (int i = t; i < 288; i += kTile)
+        out[i] = i == 256 ? 1u : sh.lit_hist[i];       // 256 = end of block, once
+    if (t < 2)
+        out[288 + t] = sh.dist_hist[t];
+    // tree reduction of the 256 partial sums (both stay below 2^32)
+    for (int off = kTile / 2; off > 0; off >>= 1) {
+        if (t < off) {
+            sh.adler_a[t] += sh.adler_a[t + off];
+            sh.adler_b[t] += sh.adler_b[t + off];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const uint32_t s1 = (1u + sh.adler_a[0]) % 65521u;
+        const uint32_t s2 = (uint32_t)(((unsigned long long)kTileBytes + sh.adler_b[0]) % 65521ull);
+        out[290] = (s2 << 16) | s1;
+        out[291] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------
+// pass B: code construction, one THREAD per tile (the algorithm is serial; ten
+// thousand tiles per strip supply the parallelism).  Each thread works in its
+// own LDS slice.
+// ------------------------------------------------------------------------
+// A tile with more than kMaxLive live literal/length symbols (noise, not a CN
+// raster: a lookup table has at most 45 values) gets a flat code instead of a
+// Huffman tree -- every live symbol ceil(log2 m) or one bit fewer, still a
+// complete prefix code, matches still pay.  That bounds the tree workspace so
+// 48 tiles are built per CU at a time.
+constexpr int kMaxLive = 144;
+struct Work {                   // Huffman workspace of one tile
+    uint32_t weight[2 * kMaxLive];
+    uint16_t parent[2 * kMaxLive];
+    uint16_t sym[kMaxLive];
+    uint8_t depth[2 * kMaxLive];
+    uint8_t lit_len[288];
+    uint8_t dist_len[32];
+    uint16_t count[18];         // codes per length
+    uint16_t next_code[18];
+    uint32_t pad;               // odd dword stride: threads of a wave hit different banks
+};
+constexpr int kBuildThreads = 48;
+
+// Length-limited canonical Huffman code of hist[0..n) -> len[], code[] (bit-reversed).
+// Two-queue construction on symbols sorted by frequency, then the Kraft fix-up
+// zlib-style encoders use to cap the depth at max_len.
+__device__ void build_code(Work &w, const uint32_t *hist, int n, int max_len, uint8_t *len,
+                           uint16_t *code_out)
+{
+    // live symbols, in symbol order; the global reads are independent of the
+    // bookkeeping, eight are kept in flight
+    int m = 0;
+    for (int s0 = 0; s0 < n; s0 += 8) {
+        uint32_t f[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            f[k] = s0 + k < n ? hist[s0 + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (s0 + k < n) {
+                len[s0 + k] = 0;
+                if (f[k]) {
+                    if (m < kMaxLive) {
+                        w.weight[m] = f[k];
+                        w.sym[m] = (uint16_t)(s0 + k);
+                    }
+                    m++;
                 }
             }
-            reinterpret_cast<uint32_t *>(sh.tile + r * kRowStride)[t & 63] = v;
         }
-        for (int i = t; i < kOutWords; i += kTile)
-            sh.out[i] = 0;
-        for (int i = t; i < 288; i += kTile)
-            sh.lit_hist[i] = 0;
-        if (t < 32)
-            sh.dist_hist[t] = 0;
     }
-    __syncthreads();
-
-    // ---- Adler-32 partial sums of row t: A = sum x, B = sum (256 - k) x_k ----
-    {
-        const uint8_t *row = sh.tile + t * kRowStride;
-        unsigned long long a = 0, b = 0;
-        for (int k = 0; k < kTile; k++) {
-            a += row[k];
-            b += (unsigned long long)(kTile - k) * row[k];
+    for (int i = 0; i <= 16; i++)
+        w.count[i] = 0;
+    if (m > kMaxLive) {
+        // flat code: 2^L - m symbols of L-1 bits, the others L bits (Kraft sum exactly 1)
+        int L = 1;
+        while ((1 << L) < m)
+            L++;
+        const int n_short = (1 << L) - m;
+        int k_live = 0;
+        for (int s = 0; s < n; s++) {
+            if (hist[s]) {
+                len[s] = (uint8_t)(k_live < n_short ? L - 1 : L);
+                k_live++;
+            }
         }
-        sh.adler_a[t] = a;
-        // weight of byte i in s2 is (n - i), n = 65536, i = 256 t + k
-        sh.adler_b[t] = b + (unsigned long long)(kTileBytes - kTile * (t + 1)) * a;
+        w.count[L - 1] = (uint16_t)n_short;
+        w.count[L] = (uint16_t)(m - n_short);
+        m = 0;                      // skip the tree
     }
-
-    // ---- pass 1: symbol statistics ----
-    parse_row<kCount>(sh, t, nullptr);
-    __syncthreads();
-
-    // ---- codes + header (thread 0) ----
-    if (t == 0) {
-        sh.lit_hist[256] = 1;           // end of block
-        build_code(sh, sh.lit_hist, kNumLit, 15, sh.lit_len, sh.lit_code);
-        build_code(sh, sh.dist_hist, kNumDist, 15, sh.dist_len, sh.dist_code);
-        BitWriter bw{ sh.out, 16 };     // bits 0..15: the zlib header
-        sh.out[0] = 0x78u | (0x9cu << 8);       // CMF = deflate, 32K window; FLG: check bits, level 2
-        write_header(sh, bw);
-        sh.header_bits = bw.pos;
+    // insertion sort by frequency (stable in symbol order)
+    for (int i = 1; i < m; i++) {
+        const uint32_t f = w.weight[i];
+        const uint16_t sy = w.sym[i];
+        int j = i;
+        while (j > 0 && w.weight[j - 1] > f) {
+            w.weight[j] = w.weight[j - 1];
+            w.sym[j] = w.sym[j - 1];
+            j--;
+        }
+        w.weight[j] = f;
+        w.sym[j] = sy;
     }
-    __syncthreads();
+    if (m == 1) {
+        len[w.sym[0]] = 1;          // a lone symbol still needs one bit
+        w.count[1] = 1;
+    }
+    if (m >= 2) {
+        // leaves 0..m-1 (sorted), internal nodes m..2m-2 in non-decreasing weight order
+        int leaf = 0, inode = m, next = m;
+        for (; next < 2 * m - 1; next++) {
+            uint32_t sum = 0;
+            for (int k = 0; k < 2; k++) {
+                int pick_;
+                if (leaf < m && (inode >= next || w.weight[leaf] <= w.weight[inode]))
+                    pick_ = leaf++;
+                else
+                    pick_ = inode++;
+                sum += w.weight[pick_];
+                w.parent[pick_] = (uint16_t)next;
+            }
+            w.weight[next] = sum;
+        }
+        w.depth[2 * m - 2] = 0;
+        for (int i = 2 * m - 3; i >= 0; i--) {
+            int d = w.depth[w.parent[i]] + 1;
+            if (d > 64)
+                d = 64;
+            w.depth[i] = (uint8_t)d;
+            if (i < m)
+                w.count[d > max_len ? max_len : d]++;
+        }
+        {
+            unsigned long long total = 0;
+            for (int i = 1; i <= max_len; i++)
+                total += (unsigned long long)w.count[i] << (max_len - i);
+            while (total > (1ull << max_len)) {
+                w.count[max_len]--;
+                for (int i = max_len - 1; i > 0; i--) {
+                    if (w.count[i]) {
+                        w.count[i]--;
+                        w.count[i + 1] += 2;
+                        break;
+                    }
+                }
+                total--;
+            }
+        }
+        int idx = m - 1;            // most frequent symbols get the shortest codes
+        for (int l = 1; l <= max_len; l++)
+            for (int c = 0; c < w.count[l]; c++)
+                len[w.sym[idx--]] = (uint8_t)l;
+    }
+    if (code_out) {
+        // canonical codes, RFC 1951 3.2.2; count[] already holds the codes per length
+        uint32_t c = 0;
+        w.count[0] = 0;
+        for (int l = 1; l <= max_len; l++) {
+            c = (c + w.count[l - 1]) << 1;
+            w.next_code[l] = (uint16_t)c;
+        }
+        for (int s = 0; s < n; s++) {
+            const int l = len[s];
+            code_out[s] = l ? (uint16_t)bitrev(w.next_code[l]++, l) : (uint16_t)0;
+        }
+    }
+}
 
-    // ---- pass 2: row bit lengths, exclusive prefix sum ----
+// the fixed canonical code of the code-length alphabet (see kClLen), bit-reversed
+__device__ __forceinline__ uint32_t cl_code_of(int v)
+{
+    if (v < 10)
+        return bitrev((uint32_t)v, 4);              // 0..9   -> 0000 .. 1001
+    if (v >= 16)
+        return bitrev((uint32_t)(v - 6), 4);        // 16..18 -> 1010 .. 1100
+    return bitrev((uint32_t)(16 + v), 5);           // 10..15 -> 11010 .. 11111
+}
+
+// serial bit writer for the block header
+struct BitWriter {
+    uint32_t *out;
+    uint32_t pos;
+    __device__ void put(uint32_t value, int nbits)
     {
-        const uint32_t bits = parse_row<kMeasure>(sh, t, nullptr);
+        const uint32_t w = pos >> 5, sh = pos & 31;
+        out[w] |= value << sh;
+        if (sh + nbits > 32)
+            out[w + 1] |= value >> (32 - sh);
+        pos += nbits;
+    }
+};
+
+__global__ __launch_bounds__(kBuildThreads) void deflate_codes_kernel(const TileJob job)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tile = blockIdx.x * kBuildThreads + threadIdx.x;
+    if (tile >= job.n_tiles)
+        return;
+    Work &w = reinterpret_cast<Work *>(smem)[threadIdx.x];
+    const uint32_t *hist = job.hist + (size_t)tile * kHistWords;
+    Book *book = reinterpret_cast<Book *>(job.books + (size_t)tile * kBookBytes);
+
+    build_code(w, hist, kNumLit, 15, w.lit_len, book->lit_code);
+    // the distance alphabet has at most two live symbols: codes 0 and 15
+    const uint32_t n_near = hist[288], n_far = hist[289];
+    for (int i = 0; i < kNumDist; i++)
+        w.dist_len[i] = 0;
+    w.dist_len[0] = n_near ? 1 : 0;
+    w.dist_len[15] = n_far ? 1 : 0;
+    book->dist_len[0] = w.dist_len[0];
+    book->dist_len[1] = w.dist_len[15];
+    book->dist_code[0] = 0;
+    book->dist_code[1] = (uint16_t)((n_near && n_far) ? 1 : 0);    // canonical: code 0 -> "0", 15 -> "1"
+    for (int s = 0; s < 288; s++)
+        book->lit_len[s] = s < kNumLit ? w.lit_len[s] : (uint8_t)0;
+
+    // ---- block header (stream bits 0..15 are the zlib header), composed in LDS: the
+    // tree weights are dead by now, their storage holds the header words ----
+    uint32_t *hdr = w.weight;
+    for (int i = 0; i < 64; i++)
+        hdr[i] = 0;
+    hdr[0] = 0x78u | (0x9cu << 8);              // CMF: deflate, 32K window; FLG: check bits, level 2
+    BitWriter bw{ hdr, 16 };
+    int hlit = kNumLit;
+    while (hlit > 257 && w.lit_len[hlit - 1] == 0)
+        hlit--;
+    int hdist = kNumDist;
+    while (hdist > 1 && w.dist_len[hdist - 1] == 0)
+        hdist--;
+    bw.put(1, 1);                               // BFINAL
+    bw.put(2, 2);                               // BTYPE = 10, dynamic Huffman
+    bw.put((uint32_t)(hlit - 257), 5);
+    bw.put((uint32_t)(hdist - 1), 5);
+    bw.put(19 - 4, 4);                          // HCLEN: all 19
+    for (int i = 0; i < 19; i++)
+        bw.put(kClLen[kClOrder[i]], 3);
+    // run-length code the hlit + hdist lengths as one sequence (RFC 1951 3.2.7)
+    const int total = hlit + hdist;
+    int i = 0;
+    while (i < total) {
+        const int v = i < hlit ? w.lit_len[i] : w.dist_len[i - hlit];
+        const int vbits = v >= 10 && v < 16 ? 5 : 4;
+        int run = 1;
+        while (i + run < total) {
+            const int j = i + run;
+            if ((j < hlit ? w.lit_len[j] : w.dist_len[j - hlit]) != v)
+                break;
+            run++;
+        }
+        int left = run;
+        if (v == 0) {
+            while (left >= 11) {
+                const int r = left > 138 ? 138 : left;
+                bw.put(cl_code_of(18), 4);
+                bw.put((uint32_t)(r - 11), 7);
+                left -= r;
+            }
+            if (left >= 3) {
+                bw.put(cl_code_of(17), 4);
+                bw.put((uint32_t)(left - 3), 3);
+                left = 0;
+            }
+        }
+        else {
+            bw.put(cl_code_of(v), vbits);
+            left--;
+            while (left >= 3) {
+                const int r = left > 6 ? 6 : left;
+                bw.put(cl_code_of(16), 4);
+                bw.put((uint32_t)(r - 3), 2);
+                left -= r;
+            }
+        }
+        while (left-- > 0)
+            bw.put(cl_code_of(v), vbits);
+        i += run;
+    }
+    for (int k = 0; k < 64; k++)
+        book->header[k] = hdr[k];
+    book->header_bits = bw.pos;
+}
+
+// ------------------------------------------------------------------------
+// pass C: measure, place and emit; one workgroup per tile
+// ------------------------------------------------------------------------
+struct SharedC {
+    uint8_t tile[kTile * kRowStride];
+    uint32_t out[kOutWords];
+    uint8_t lit_len[288];
+    uint16_t lit_code[288];
+    uint32_t row_bits[kTile];
+    uint32_t scan[kTile];
+    uint32_t header_bits, total_bits, stream_bytes, use_stored;
+    unsigned long long slot;
+};
+
+__global__ __launch_bounds__(kTile) void deflate_emit_kernel(const TileJob job)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    SharedC &sh = *reinterpret_cast<SharedC *>(smem);
+    const int t = threadIdx.x;
+    const uint32_t tiles = job.across * job.down;
+    const uint32_t raster = blockIdx.x / tiles;
+    const uint32_t tix = blockIdx.x - raster * tiles;
+    const uint32_t ty = tix / job.across, tx = tix - ty * job.across;
+    const Book *book = reinterpret_cast<const Book *>(job.books + (size_t)blockIdx.x * kBookBytes);
+
+    load_tile(job, job.rasters[raster], tx, ty, sh.tile, t);
+    for (int i = t; i < kOutWords; i += kTile)
+        sh.out[i] = i < 64 ? book->header[i] : 0u;
+    for (int i = t; i < 288; i += kTile) {
+        sh.lit_len[i] = book->lit_len[i];
+        sh.lit_code[i] = book->lit_code[i];
+    }
+    CodeView cv;
+    cv.lit_len = sh.lit_len;
+    cv.lit_code = sh.lit_code;
+    cv.dist_len[0] = book->dist_len[0];
+    cv.dist_len[1] = book->dist_len[1];
+    cv.dist_code[0] = book->dist_code[0];
+    cv.dist_code[1] = book->dist_code[1];
+    if (t == 0)
+        sh.header_bits = book->header_bits;
+    __syncthreads();
+
+    RowMasks m;
+    row_masks(sh.tile, t, m);
+
+    // row bit lengths, inclusive prefix sum
+    {
+        const uint32_t bits = parse_row<kMeasure>(sh.tile, t, m, nullptr, nullptr, &cv, nullptr);
         sh.row_bits[t] = bits;
         sh.scan[t] = bits;
     }
@@ -489,27 +732,24 @@ __global__ __launch_bounds__(kTile) void deflate_tiles_kernel(const TileJob job)
         __syncthreads();
     }
     if (t == 0) {
-        const uint32_t body = sh.scan[kTile - 1];
-        sh.total_bits = sh.header_bits + body + sh.lit_len[256];
+        sh.total_bits = sh.header_bits + sh.scan[kTile - 1] + sh.lit_len[256];
         const uint32_t bytes = (sh.total_bits + 7) / 8 + 4;
-        sh.use_stored = bytes > (uint32_t)kMaxStream - 64u || sh.header_bits > 2048u * 8u;
+        sh.use_stored = bytes > (uint32_t)kMaxStream - 64u;
         sh.stream_bytes = sh.use_stored ? (uint32_t)kMaxStream : bytes;
     }
     __syncthreads();
 
     if (!sh.use_stored) {
-        // ---- pass 3: emit ----
         RowEmitter em{ sh.out, sh.header_bits + sh.scan[t] - sh.row_bits[t], 0ull, 0 };
-        parse_row<kEmit>(sh, t, &em);
+        parse_row<kEmit>(sh.tile, t, m, nullptr, nullptr, &cv, &em);
         if (t == kTile - 1)
-            em.put(sh.lit_code[256], sh.lit_len[256]);
+            em.put(sh.lit_code[256], sh.lit_len[256]);      // end of block
         em.finish();
     }
     else {
-        // ---- stored fallback: two blocks of 32768 bytes (LEN is 16 bit) ----
-        __syncthreads();
+        // stored fallback: two blocks of 32768 bytes (LEN is 16 bit)
         uint8_t *o = reinterpret_cast<uint8_t *>(sh.out);
-        for (int i = t; i < kOutWords; i += kTile)
+        for (int i = t; i < 64; i += kTile)
             sh.out[i] = 0;
         __syncthreads();
         if (t == 0) {
@@ -527,8 +767,7 @@ __global__ __launch_bounds__(kTile) void deflate_tiles_kernel(const TileJob job)
         __syncthreads();
         {
             // row t = bytes 256 t .. 256 t + 255 of the tile; block b holds rows 128 b ..
-            const int b = t >> 7;
-            uint8_t *dst = o + 2 + b * (5 + 32768) + 5 + (t & 127) * kTile;
+            uint8_t *dst = o + 2 + (t >> 7) * (5 + 32768) + 5 + (t & 127) * kTile;
             const uint8_t *row = sh.tile + t * kRowStride;
             for (int k = 0; k < kTile; k++)
                 dst[k] = row[k];
@@ -536,16 +775,8 @@ __global__ __launch_bounds__(kTile) void deflate_tiles_kernel(const TileJob job)
     }
     __syncthreads();
 
-    // ---- Adler-32 trailer, slot reservation ----
     if (t == 0) {
-        unsigned long long s1 = 1, s2 = (unsigned long long)kTileBytes;
-        for (int i = 0; i < kTile; i++) {
-            s1 += sh.adler_a[i];
-            s2 += sh.adler_b[i] % 65521ull;
-        }
-        s1 %= 65521ull;
-        s2 %= 65521ull;
-        const uint32_t adler = (uint32_t)((s2 << 16) | s1);
+        const uint32_t adler = job.hist[(size_t)blockIdx.x * kHistWords + 290];
         uint8_t *o = reinterpret_cast<uint8_t *>(sh.out);
         const uint32_t at = sh.stream_bytes - 4;
         o[at] = (uint8_t)(adler >> 24);
@@ -555,7 +786,7 @@ __global__ __launch_bounds__(kTile) void deflate_tiles_kernel(const TileJob job)
         const unsigned long long need = (sh.stream_bytes + (kSlotAlign - 1)) & ~(unsigned long long)(kSlotAlign - 1);
         const unsigned long long slot = atomicAdd(job.cursor, need);
         sh.slot = slot;
-        uint32_t *te = job.table + ((size_t)raster * tiles + tix) * 2;
+        uint32_t *te = job.table + (size_t)blockIdx.x * 2;
         if (slot + need <= job.arena_cap) {
             te[0] = (uint32_t)slot;
             te[1] = sh.stream_bytes;
@@ -619,16 +850,42 @@ int gcn10_gpu_deflate_strip(gcn10_gpu_ctx *ctx, const uint8_t *const *rasters_de
     const uint64_t nblocks = (uint64_t)job.across * job.down * (uint64_t)n_rasters;
     if (nblocks > 0x7fffffffull)
         return fail(GCN10_E_INVAL, "gcn10_gpu_deflate_strip: too many tiles");
-    hipStream_t s = as_stream(ctx, stream);
-    static_assert(sizeof(Shared) <= 160 * 1024, "tile + output image must fit the CU's 160 KiB of LDS");
+    job.n_tiles = (uint32_t)nblocks;
+
+    // per-tile statistics and code books: workspace owned by the context
+    const size_t need = (size_t)nblocks * ((size_t)kHistWords * 4 + (size_t)kBookBytes);
+    if (need > ctx->deflate_ws_cap) {
+        HIP_TRY(hipDeviceSynchronize());        // the old workspace may still be in use
+        if (ctx->deflate_ws)
+            HIP_TRY(hipFree(ctx->deflate_ws));
+        ctx->deflate_ws = nullptr;
+        ctx->deflate_ws_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->deflate_ws, need));
+        ctx->deflate_ws_cap = need;
+    }
+    job.hist = reinterpret_cast<uint32_t *>(ctx->deflate_ws);
+    job.books = reinterpret_cast<uint8_t *>(ctx->deflate_ws) + (size_t)nblocks * kHistWords * 4;
+
+    static_assert(sizeof(SharedC) <= 160 * 1024, "tile + output image must fit the CU's 160 KiB of LDS");
+    static_assert(sizeof(Work) * kBuildThreads <= 160 * 1024, "code construction slices must fit LDS");
+    static_assert(kBookBytes % 4 == 0, "code books are dword aligned");
     if (!ctx->deflate_ready) {
         // more than 64 KiB of dynamic LDS has to be asked for, once per device
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(deflate_tiles_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Shared)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(deflate_stats_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SharedA)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(deflate_codes_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(sizeof(Work) * kBuildThreads)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(deflate_emit_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SharedC)));
         ctx->deflate_ready = true;
     }
+    hipStream_t s = as_stream(ctx, stream);
     HIP_TRY(hipMemsetAsync(cursor_dev, 0, sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(deflate_tiles_kernel, dim3((uint32_t)nblocks), dim3(kTile), sizeof(Shared), s, job);
+    hipLaunchKernelGGL(deflate_stats_kernel, dim3((uint32_t)nblocks), dim3(kTile), sizeof(SharedA), s, job);
+    hipLaunchKernelGGL(deflate_codes_kernel, dim3(((uint32_t)nblocks + kBuildThreads - 1) / kBuildThreads),
+                       dim3(kBuildThreads), sizeof(Work) * kBuildThreads, s, job);
+    hipLaunchKernelGGL(deflate_emit_kernel, dim3((uint32_t)nblocks), dim3(kTile), sizeof(SharedC), s, job);
     HIP_TRY(hipGetLastError());
     return GCN10_OK;
 }

@@ -755,6 +755,8 @@ void gcn10_gpu_destroy(gcn10_gpu_ctx *ctx)
         (void)hipFree(ctx->d_lut1);
     if (ctx->d_hx)
         (void)hipFree(ctx->d_hx);
+    if (ctx->deflate_ws)
+        (void)hipFree(ctx->deflate_ws);
     delete ctx;
 }
 

@@ -47,7 +47,9 @@ struct gcn10_gpu_ctx {
     int ilp1 = 2;           // same, single-table kernel (1, 2, 4)
     int nontemporal = 1;
     int xcd_slabs = 1;
-    bool deflate_ready = false;     // LDS attribute of the tile encoder set on this device
+    bool deflate_ready = false;     // LDS attributes of the tile encoder set on this device
+    void *deflate_ws = nullptr;     // per-tile statistics + code books of the tile encoder
+    size_t deflate_ws_cap = 0;
 };
 
 #endif

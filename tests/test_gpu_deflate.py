@@ -31,6 +31,9 @@ def _rasters(kind, H, W, seed):
         for k, thr in enumerate([1e-1, 3e-2, 1e-2, 3e-3, 1e-3, 3e-4, 1e-4, 5e-5, 2e-5]):
             v[idx < thr] = k
         return v
+    if kind == "manyvals":          # > 144 live symbols but long runs: the flat-code path
+        a = rng.integers(0, 256, size=((H + 7) // 8, (W + 7) // 8), dtype=np.uint8)
+        return np.repeat(np.repeat(a, 8, axis=0), 8, axis=1)[:H, :W].copy()
     raise ValueError(kind)
 
 
@@ -56,7 +59,7 @@ def _check(engine, rasters, W, H):
     return total
 
 
-@pytest.mark.parametrize("kind", ["uniform", "zeros", "patches", "noisy", "random", "rows", "skewed"])
+@pytest.mark.parametrize("kind", ["uniform", "zeros", "patches", "noisy", "random", "rows", "skewed", "manyvals"])
 def test_streams_inflate_to_the_tiles(engine, kind):
     H, W = 512, 768
     img = _rasters(kind, H, W, 1)
@@ -69,7 +72,7 @@ def test_streams_inflate_to_the_tiles(engine, kind):
         assert size < 6 * 300           # a constant tile: 256 one-token rows, ~250 B (266:1)
     if kind == "random":
         assert size == 6 * 65552        # stored fallback, never worse than raw + 16 B
-    if kind in ("patches", "noisy", "rows", "skewed"):
+    if kind in ("patches", "noisy", "rows", "skewed", "manyvals"):
         assert size < 2.0 * ref         # within 2x of zlib level 6 on CN-like data
 
 
