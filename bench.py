@@ -77,7 +77,8 @@ def cpu_baseline(workload: str, size: int):
     this process touches the GPU."""
     cond_mask, table_mask, _ = WORKLOADS[workload]
     n_out = bin(cond_mask).count("1") * bin(table_mask).count("1")
-    rows = max(16, min(size, (4000 if n_out == 1 else 12000 // n_out)))
+    # about 10-30 s of CPU work per worker: 16000 rows for one raster, 2000 rows for all 18
+    rows = max(16, min(size, (16000 if n_out == 1 else 36000 // n_out)))
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--width", str(size),
            "--rows", str(rows), "--cond-mask", str(cond_mask), "--table-mask", str(table_mask)]
     try:
@@ -205,7 +206,7 @@ def main():
     elapsed = grp.max(elapsed)
 
     kernel_ms = [eng.elapsed_ms(a, b) for a, b in ev]
-    kname = "calculate_cn_kernel" if preresampled else eng.last_kernel_name()
+    kname = "calculate_cn_kernel<true>" if preresampled else eng.last_kernel_name()
     launches = 1 if preresampled else (size + strip - 1) // strip
     avg_launch_s = float(np.mean(kernel_ms)) / 1e3 / launches
     if preresampled:

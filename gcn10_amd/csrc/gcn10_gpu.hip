@@ -1196,7 +1196,10 @@ int gcn10_gpu_cn_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, int rows,
         if (!fn)
             return fail(GCN10_E_INVAL, "gcn10_gpu_cn_strip: no kernel for ilp=%d", ilp);
         hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), 0, s, p);
-        ctx->last_kernel = single ? "cn_strip_lut1" : "cn_strip_lut16";
+        // the instantiation's name as rocprofv3 prints it: <KIND, COND_MASK, ALL_TABLES, ILP, NT>
+        snprintf(ctx->kernel_name, sizeof ctx->kernel_name, "cn_strip_kernel<%d, %u, %s, %d, %s>",
+                 single ? 1 : 0, cond_mask, (all || single) ? "true" : "false", ilp, nt ? "true" : "false");
+        ctx->last_kernel = ctx->kernel_name;
     }
     HIP_TRY(hipGetLastError());
     return GCN10_OK;

@@ -41,6 +41,7 @@ struct gcn10_gpu_ctx {
     uint32_t hx_W = 0;
     uint32_t hx_rows = 0;
     const char *last_kernel = "";
+    char kernel_name[96] = "";
     // tuning knobs (gcn10_gpu_set_option); defaults = the round-1 measured best
     int grid_blocks_per_cu = 8;
     int ilp16 = 2;          // sub-chunks per loop trip, all-tables kernel (1, 2)

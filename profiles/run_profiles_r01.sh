@@ -1,3 +1,5 @@
+# Round-1 profile recipe (run on the GPU box through gpurun): kernel trace + two PMC passes of
+# the default bench command, all with --no-cpu-baseline (no child processes under rocprofv3).
 set -e
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
@@ -8,4 +10,3 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- py
 echo fetch done
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_write.log 2>&1
 echo write done
-ls -R $R/gpurun_out | head -50

@@ -95,12 +95,12 @@ def test_all_65536_pairs_both_kernels(eng9, tables):
     sgt = [0.5, 1.0, 0.0, 0.0, 0.0, -1.0]
     want = oc.process_block_mem(esa, gt, coarse, sgt, tables)
     got = eng9.process_block_mem(esa, gt, coarse, sgt)
-    assert eng9.last_kernel_name() == "cn_strip_lut16"
+    assert eng9.last_kernel_name().startswith("cn_strip_kernel<0,")
     assert np.array_equal(got, want)
     # single-table kernel, every table
     for k in range(9):
         g1 = eng9.process_block_mem(esa, gt, coarse, sgt, cond_mask=3, table_mask=1 << k)
-        assert eng9.last_kernel_name() == "cn_strip_lut1"
+        assert eng9.last_kernel_name().startswith("cn_strip_kernel<1,")
         assert np.array_equal(g1[k], want[k]) and np.array_equal(g1[9 + k], want[9 + k])
 
 
@@ -267,7 +267,7 @@ def test_full_size_strips_and_single_table_kernels_agree(eng9, full_tile):
             e.cn_strip(ft["bufs"]["esa"].at(y0 * W), W, 4000, ft["bufs"]["cj"].at(4 * y0),
                        1 << c, 1 << k, ptrs, s)
         e.sync(s)
-        assert e.last_kernel_name() == "cn_strip_lut1"
+        assert e.last_kernel_name().startswith("cn_strip_kernel<1,")
         a = e.download(tmp.ptr, (H * W,))
         b = e.download(ft["outs"][r].ptr, (H * W,))
         assert np.array_equal(a, b)
