@@ -44,10 +44,12 @@ struct gcn10_gpu_ctx {
     char kernel_name[96] = "";
     // tuning knobs (gcn10_gpu_set_option); defaults = the round-1 measured best
     int grid_blocks_per_cu = 8;
-    int ilp16 = 2;          // sub-chunks per loop trip, all-tables kernel (1, 2)
+    int ilp16 = 1;          // sub-chunks per loop trip, all-tables kernel (1, 2)
     int ilp1 = 2;           // same, single-table kernel (1, 2, 4)
     int nontemporal = 1;
     int xcd_slabs = 1;
+    int prefetch = -1;      // loads of the next trip issued before the current one is consumed:
+                            // -1 = per kernel default (on for all-tables, off for single-table)
     bool deflate_ready = false;     // LDS attributes of the tile encoder set on this device
     void *deflate_ws = nullptr;     // per-tile statistics + code books of the tile encoder
     size_t deflate_ws_cap = 0;

@@ -14,6 +14,21 @@ int gcn10_tiff_read_window(struct gcn10_tiff *t, int xoff, int yoff, int xcount,
                            uint8_t *dst, size_t dst_stride, char *err, size_t errcap);
 
 
+/* pool.c: fixed thread pool (tile compression, tile decode) */
+typedef struct gcn10_pool gcn10_pool;
+typedef void (*gcn10_job_fn)(void *arg);
+gcn10_pool *gcn10_pool_create(int n_threads);
+void gcn10_pool_submit(gcn10_pool *p, gcn10_job_fn fn, void *arg);
+void gcn10_pool_destroy(gcn10_pool *p);     /* drains the queue first */
+
+/* Like gcn10_tiff_read_window / gcn10_raster_read, with the tiles or strips of the
+ * window decoded concurrently on `pool` (NULL = on the calling thread). */
+int gcn10_tiff_read_window_mt(struct gcn10_tiff *t, int xoff, int yoff, int xcount, int ycount,
+                              uint8_t *dst, size_t dst_stride, gcn10_pool *pool, char *err,
+                              size_t errcap);
+int gcn10_raster_read_mt(gcn10_raster *r, int xoff, int yoff, int xcount, int ycount, uint8_t *dst,
+                         gcn10_pool *pool, char *err, size_t errcap);
+
 /* gpuapi.c: include/gcn10_gpu.h bound with dlopen */
 struct gcn10_gpu_api {
     bool loaded;
@@ -51,11 +66,5 @@ struct gcn10_gpu_api {
 };
 const struct gcn10_gpu_api *gcn10_gpu_api_get(char *err, size_t errcap);
 
-/* pool.c: fixed thread pool for tile compression */
-typedef struct gcn10_pool gcn10_pool;
-typedef void (*gcn10_job_fn)(void *arg);
-gcn10_pool *gcn10_pool_create(int n_threads);
-void gcn10_pool_submit(gcn10_pool *p, gcn10_job_fn fn, void *arg);
-void gcn10_pool_destroy(gcn10_pool *p);     /* drains the queue first */
 
 #endif

@@ -529,7 +529,9 @@ static int process_block(struct worker *w, int block_id)
         /* landcover rows straight into the pinned strip (replaces the malloc +
          * GDALRasterIO of src/raster.c:169-178) */
         double t_r0 = now_seconds();
-        int read_rc = gcn10_raster_read(w->esa, xoff, yoff + y0, W, rows, b->h_esa, err, sizeof err);
+        /* the strip's landcover tiles are decoded concurrently on the I/O pool */
+        int read_rc = gcn10_raster_read_mt(w->esa, xoff, yoff + y0, W, rows, b->h_esa, r->pool, err,
+                                           sizeof err);
 
         w->t_read += now_seconds() - t_r0;
         if (read_rc != 0) {
@@ -938,7 +940,7 @@ int gcn10_run(const gcn10_run_options *opt)
         r->n_blocks = kept;
     }
 
-    if (!r->null_sink) {
+    {
         long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
         int nthreads = r->cfg.io_threads > 0 ? r->cfg.io_threads : (int)(ncpu > 2 ? ncpu - 1 : 1);
 

@@ -317,6 +317,12 @@ const gcn10_georef *gcn10_raster_georef(const gcn10_raster *r)
 int gcn10_raster_read(gcn10_raster *r, int xoff, int yoff, int xcount, int ycount, uint8_t *dst,
                       char *err, size_t errcap)
 {
+    return gcn10_raster_read_mt(r, xoff, yoff, xcount, ycount, dst, NULL, err, errcap);
+}
+
+int gcn10_raster_read_mt(gcn10_raster *r, int xoff, int yoff, int xcount, int ycount, uint8_t *dst,
+                         gcn10_pool *pool, char *err, size_t errcap)
+{
     if (xoff < 0 || yoff < 0 || xcount <= 0 || ycount <= 0 || xoff + xcount > r->xsize ||
         yoff + ycount > r->ysize) {
         snprintf(err, errcap, "window %d,%d %dx%d outside raster %dx%d", xoff, yoff, xcount, ycount,
@@ -324,8 +330,8 @@ int gcn10_raster_read(gcn10_raster *r, int xoff, int yoff, int xcount, int ycoun
         return -1;
     }
     if (r->tiff)
-        return gcn10_tiff_read_window(r->tiff, xoff, yoff, xcount, ycount, dst, (size_t)xcount, err,
-                                      errcap);
+        return gcn10_tiff_read_window_mt(r->tiff, xoff, yoff, xcount, ycount, dst, (size_t)xcount, pool,
+                                         err, errcap);
 
     /* VRT: start from 0 (the band's NoDataValue in the shipped VRT) and paint
      * the sources in file order */
@@ -347,8 +353,8 @@ int gcn10_raster_read(gcn10_raster *r, int xoff, int yoff, int xcount, int ycoun
             return -1;
         at = dst + (size_t)(y0 - yoff) * (size_t)xcount + (size_t)(x0 - xoff);
         if (s->nodata < 0) {
-            rc = gcn10_tiff_read_window(t, s->sx + (x0 - s->dx), s->sy + (y0 - s->dy), x1 - x0,
-                                        y1 - y0, at, (size_t)xcount, err, errcap);
+            rc = gcn10_tiff_read_window_mt(t, s->sx + (x0 - s->dx), s->sy + (y0 - s->dy), x1 - x0,
+                                           y1 - y0, at, (size_t)xcount, pool, err, errcap);
         }
         else {
             /* ComplexSource with NODATA: source pixels equal to it stay transparent */
@@ -360,8 +366,8 @@ int gcn10_raster_read(gcn10_raster *r, int xoff, int yoff, int xcount, int ycoun
                 rc = -1;
             }
             else {
-                rc = gcn10_tiff_read_window(t, s->sx + (x0 - s->dx), s->sy + (y0 - s->dy), x1 - x0,
-                                            y1 - y0, tmp, w, err, errcap);
+                rc = gcn10_tiff_read_window_mt(t, s->sx + (x0 - s->dx), s->sy + (y0 - s->dy), x1 - x0,
+                                               y1 - y0, tmp, w, pool, err, errcap);
                 if (rc == 0)
                     for (size_t y = 0; y < h; y++)
                         for (size_t x = 0; x < w; x++)

@@ -589,13 +589,83 @@ static int decode_chunk(struct gcn10_tiff *t, uint64_t idx, unsigned char *buf, 
     return 0;
 }
 
-int gcn10_tiff_read_window(struct gcn10_tiff *t, int xoff, int yoff, int xcount, int ycount,
-                           uint8_t *dst, size_t dst_stride, char *err, size_t errcap)
+/* one chunk (tile or strip) of a window read: decode and copy the overlap */
+struct chunk_job {
+    struct gcn10_tiff *t;
+    uint32_t cx, cy;
+    int xoff, yoff, xcount, ycount;
+    uint8_t *dst;
+    size_t dst_stride;
+    /* completion */
+    pthread_mutex_t *mu;
+    pthread_cond_t *cv;
+    int *pending;
+    int *failed;
+};
+
+static int read_chunk(const struct chunk_job *j)
 {
+    /* per-thread decode buffers, reused across chunks */
+    static __thread unsigned char *raw = NULL, *scratch = NULL;
+    static __thread size_t raw_cap = 0, scratch_cap = 0;
+    struct gcn10_tiff *t = j->t;
     size_t rawcap = (size_t)t->cw * t->ch * t->spp;
-    unsigned char *raw, *scratch = NULL;
-    size_t scratch_cap = 0;
-    int rc = 0;
+    uint32_t y_lo = j->cy * t->ch, x_lo = j->cx * t->cw;
+    uint32_t rows_in_chunk = t->tiled ? t->ch : (y_lo + t->ch <= t->height ? t->ch : t->height - y_lo);
+    uint32_t ys = (uint32_t)j->yoff > y_lo ? (uint32_t)j->yoff : y_lo;
+    uint32_t ye = (uint32_t)(j->yoff + j->ycount) < y_lo + rows_in_chunk ? (uint32_t)(j->yoff + j->ycount)
+                                                                         : y_lo + rows_in_chunk;
+    uint32_t xs = (uint32_t)j->xoff > x_lo ? (uint32_t)j->xoff : x_lo;
+    uint32_t xe = (uint32_t)(j->xoff + j->xcount) < x_lo + t->cw ? (uint32_t)(j->xoff + j->xcount)
+                                                                 : x_lo + t->cw;
+
+    if (rawcap > raw_cap) {
+        unsigned char *g = realloc(raw, rawcap);
+
+        if (!g)
+            return -1;
+        raw = g;
+        raw_cap = rawcap;
+    }
+    if (decode_chunk(t, (uint64_t)j->cy * t->across + j->cx, raw, rawcap, &scratch, &scratch_cap,
+                     rows_in_chunk) != 0)
+        return -1;
+    for (uint32_t y = ys; y < ye; y++) {
+        const unsigned char *s = raw + ((size_t)(y - y_lo) * t->cw + (xs - x_lo)) * t->spp;
+        uint8_t *d = j->dst + (size_t)(y - (uint32_t)j->yoff) * j->dst_stride + (xs - (uint32_t)j->xoff);
+
+        if (t->spp == 1) {
+            memcpy(d, s, xe - xs);
+        }
+        else {
+            for (uint32_t x = 0; x < xe - xs; x++)
+                d[x] = s[(size_t)x * t->spp];
+        }
+    }
+    return 0;
+}
+
+static void chunk_job_run(void *arg)
+{
+    struct chunk_job *j = arg;
+    int rc = read_chunk(j);
+
+    pthread_mutex_lock(j->mu);
+    if (rc != 0)
+        *j->failed = 1;
+    if (--*j->pending == 0)
+        pthread_cond_broadcast(j->cv);
+    pthread_mutex_unlock(j->mu);
+    free(j);
+}
+
+int gcn10_tiff_read_window_mt(struct gcn10_tiff *t, int xoff, int yoff, int xcount, int ycount,
+                              uint8_t *dst, size_t dst_stride, gcn10_pool *pool, char *err,
+                              size_t errcap)
+{
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    pthread_cond_t cv = PTHREAD_COND_INITIALIZER;
+    int pending = 0, failed = 0;
 
     if (xoff < 0 || yoff < 0 || xcount <= 0 || ycount <= 0 ||
         (uint64_t)xoff + (uint64_t)xcount > t->width || (uint64_t)yoff + (uint64_t)ycount > t->height) {
@@ -603,49 +673,40 @@ int gcn10_tiff_read_window(struct gcn10_tiff *t, int xoff, int yoff, int xcount,
                  t->width, t->height);
         return -1;
     }
-    raw = malloc(rawcap ? rawcap : 1);
-    if (!raw) {
-        snprintf(err, errcap, "out of memory reading raster window");
-        return -1;
-    }
-    for (uint32_t cy = (uint32_t)yoff / t->ch; cy <= (uint32_t)(yoff + ycount - 1) / t->ch && !rc; cy++) {
-        uint32_t y_lo = cy * t->ch;
-        uint32_t rows_in_chunk = t->tiled ? t->ch
-                                          : (y_lo + t->ch <= t->height ? t->ch : t->height - y_lo);
-        uint32_t ys = (uint32_t)yoff > y_lo ? (uint32_t)yoff : y_lo;
-        uint32_t ye = (uint32_t)(yoff + ycount) < y_lo + rows_in_chunk ? (uint32_t)(yoff + ycount)
-                                                                       : y_lo + rows_in_chunk;
-
+    for (uint32_t cy = (uint32_t)yoff / t->ch; cy <= (uint32_t)(yoff + ycount - 1) / t->ch; cy++) {
         for (uint32_t cx = (uint32_t)xoff / t->cw; cx <= (uint32_t)(xoff + xcount - 1) / t->cw; cx++) {
-            uint32_t x_lo = cx * t->cw;
-            uint32_t xs = (uint32_t)xoff > x_lo ? (uint32_t)xoff : x_lo;
-            uint32_t xe = (uint32_t)(xoff + xcount) < x_lo + t->cw ? (uint32_t)(xoff + xcount)
-                                                                   : x_lo + t->cw;
+            struct chunk_job job = { t, cx, cy, xoff, yoff, xcount, ycount, dst, dst_stride,
+                                     &mu, &cv, &pending, &failed };
+            struct chunk_job *j = pool ? malloc(sizeof *j) : NULL;
 
-            if (decode_chunk(t, (uint64_t)cy * t->across + cx, raw, rawcap, &scratch, &scratch_cap,
-                             rows_in_chunk) != 0) {
-                snprintf(err, errcap, "gdalrasterio error: cannot decode %s %u,%u",
-                         t->tiled ? "tile" : "strip", cx, cy);
-                rc = -1;
-                break;
+            if (!j) {               /* no pool (or no memory for the job): decode here */
+                if (read_chunk(&job) != 0)
+                    failed = 1;
+                continue;
             }
-            for (uint32_t y = ys; y < ye; y++) {
-                const unsigned char *s = raw + ((size_t)(y - y_lo) * t->cw + (xs - x_lo)) * t->spp;
-                uint8_t *d = dst + (size_t)(y - (uint32_t)yoff) * dst_stride + (xs - (uint32_t)xoff);
-
-                if (t->spp == 1) {
-                    memcpy(d, s, xe - xs);
-                }
-                else {
-                    for (uint32_t x = 0; x < xe - xs; x++)
-                        d[x] = s[(size_t)x * t->spp];
-                }
-            }
+            *j = job;
+            pthread_mutex_lock(&mu);
+            pending++;
+            pthread_mutex_unlock(&mu);
+            gcn10_pool_submit(pool, chunk_job_run, j);
         }
     }
-    free(raw);
-    free(scratch);
-    return rc;
+    pthread_mutex_lock(&mu);
+    while (pending > 0)
+        pthread_cond_wait(&cv, &mu);
+    pthread_mutex_unlock(&mu);
+    if (failed) {
+        snprintf(err, errcap, "gdalrasterio error: cannot decode a %s of the window %d,%d %dx%d",
+                 t->tiled ? "tile" : "strip", xoff, yoff, xcount, ycount);
+        return -1;
+    }
+    return 0;
+}
+
+int gcn10_tiff_read_window(struct gcn10_tiff *t, int xoff, int yoff, int xcount, int ycount,
+                           uint8_t *dst, size_t dst_stride, char *err, size_t errcap)
+{
+    return gcn10_tiff_read_window_mt(t, xoff, yoff, xcount, ycount, dst, dst_stride, NULL, err, errcap);
 }
 
 /* ------------------------------------------------------------------------ */

@@ -16,7 +16,7 @@ import numpy as np
 from . import host as _host
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgcn10_gpu.so")
+LIB_PATH = os.environ.get("GCN10_GPU_LIB") or os.path.join(_HERE, "libgcn10_gpu.so")
 _lib = None
 
 N_TABLES = 9

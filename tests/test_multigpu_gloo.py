@@ -44,16 +44,22 @@ def test_gloo_world_size_two(tmp_path):
         total = g.sum(10.0 * (g.rank + 1))
         mine = shard.blocks_for_rank(list(range(10, 21)), g.rank, g.world)
         g.barrier()
-        print(json.dumps({"rank": g.rank, "world": g.world, "worst": worst, "total": total, "mine": mine}))
+        with open(os.path.join(%r, "rank%%d.json" %% g.rank), "w") as f:     # one file per rank:
+            json.dump({"rank": g.rank, "world": g.world, "worst": worst,      # stdout of two ranks interleaves
+                       "total": total, "mine": mine}, f)
         g.close()
-    """ % ROOT))
+    """ % (ROOT, str(tmp_path))))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    import socket
+    with socket.socket() as sk:           # a port nobody holds right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29571", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     import json
-    recs = sorted((json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")), key=lambda r: r["rank"])
+    recs = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
     assert [r["rank"] for r in recs] == [0, 1] and all(r["world"] == 2 for r in recs)
     assert all(r["worst"] == 2.0 and r["total"] == 30.0 for r in recs)       # max / sum over ranks
     assert recs[0]["mine"] == [10, 12, 14, 16, 18, 20] and recs[1]["mine"] == [11, 13, 15, 17, 19]

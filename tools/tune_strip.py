@@ -78,10 +78,13 @@ def main():
     ref = {}
     for name, cm, tm, rasters, ilp_key, ilps in workloads:
         alg = gpu.strip_algorithmic_bytes(size, size, hs, hs, cm, tm)
-        grids = [4, 8, 16] if not a.quick else [8]
-        for ilp, nt, xcd, bpc in itertools.product(ilps, [1, 0], [1, 0], grids):
+        grids = [4, 8, 16, 32] if not a.quick else [8, 16]
+        for ilp, nt, xcd, bpc, pf in itertools.product(ilps, [1, 0], [1, 0], grids, [1, 0]):
             if a.quick and (nt == 0 or xcd == 0):
                 continue
+            if pf and ilp > 2:
+                continue
+            eng.set_option("prefetch", pf)
             eng.set_option(ilp_key, ilp)
             eng.set_option("nontemporal", nt)
             eng.set_option("xcd_slabs", xcd)
@@ -89,7 +92,7 @@ def main():
             ms = time_it(cm, tm, rasters)
             d = digest(rasters[:3])
             ref.setdefault(name, d)
-            rec = {"workload": name, "ilp": ilp, "nt": nt, "xcd_slabs": xcd, "blocks_per_cu": bpc,
+            rec = {"workload": name, "ilp": ilp, "pf": pf, "nt": nt, "xcd_slabs": xcd, "blocks_per_cu": bpc,
                    "ms": round(ms, 4), "GBps": round(alg / ms / 1e6, 1),
                    "frac": round(alg / ms / 1e6 / 8000, 4), "ok": d == ref[name]}
             results.append(rec)
