@@ -40,7 +40,16 @@ else
 cli:
 endif
 
+# host library under AddressSanitizer + UBSan, and the host test files run against it
+asan-host:
+	$(CC) -std=c99 -D_GNU_SOURCE -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined \
+	    -fno-sanitize-recover=undefined -fPIC -ffp-contract=off -Iinclude -pthread -shared \
+	    -o /tmp/libgcn10_host_asan.so $(HOSTLIBSRC) -lm -lz -ldl
+	LD_PRELOAD="$$($(CC) -print-file-name=libasan.so) $$($(CC) -print-file-name=libubsan.so)" \
+	    ASAN_OPTIONS=detect_leaks=0 GCN10_HOST_LIB=/tmp/libgcn10_host_asan.so \
+	    python -m pytest tests/test_host.py tests/test_host_io.py tests/test_host_fuzz.py -q
+
 clean:
 	rm -f $(PKG)/*.so bin/gcn10
 	$(MAKE) -C oracle clean
-.PHONY: all gpu host cli oracle clean
+.PHONY: all gpu host cli oracle clean asan-host

@@ -23,6 +23,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -44,6 +45,7 @@ struct gcn10_tiff {
     uint32_t across, down;      /* chunks per row / column */
     uint64_t *offsets, *counts;
     uint64_t n_chunks;
+    uint64_t file_size;
     double gt[6];
     gcn10_georef georef;
 };
@@ -99,7 +101,8 @@ static unsigned char *entry_bytes(struct gcn10_tiff *t, const unsigned char *e, 
     const unsigned char *valp = e + (t->big ? 12 : 8);
     unsigned char *buf;
 
-    if (!ts || count > (1ull << 31) / ts)
+    /* a value array can never be larger than the file that holds it */
+    if (!ts || count > (1ull << 31) / ts || ts * count > t->file_size)
         return NULL;
     *nbytes = (size_t)(ts * count);
     buf = malloc(*nbytes ? *nbytes : 1);
@@ -190,6 +193,13 @@ struct gcn10_tiff *gcn10_tiff_open_reader(const char *path, char *err, size_t er
     if (t->fd < 0 || pread_all(t->fd, hdr, 8, 0) != 0) {
         snprintf(err, errcap, "gdal open failed: %s", path);        /* src/raster.c:121 */
         goto fail;
+    }
+    {
+        struct stat st;
+
+        if (fstat(t->fd, &st) != 0 || st.st_size < 8)
+            goto badfile;
+        t->file_size = (uint64_t)st.st_size;
     }
     if (hdr[0] == 'I' && hdr[1] == 'I')
         t->swap = false;
@@ -348,6 +358,9 @@ struct gcn10_tiff *gcn10_tiff_open_reader(const char *path, char *err, size_t er
     t->across = (t->width + t->cw - 1) / t->cw;
     t->down = (t->height + t->ch - 1) / t->ch;
     if ((uint64_t)t->across * t->down > t->n_chunks)
+        goto badfile;
+    if (t->spp == 0 || t->spp > 16 || (uint64_t)t->cw * t->ch * t->spp > (1ull << 30) ||
+        t->width > 0x7fffffffu || t->height > 0x7fffffffu)
         goto badfile;
     switch (t->compression) {
     case 1: case 5: case 8: case 32946: case 32773:
@@ -539,6 +552,8 @@ static int decode_chunk(struct gcn10_tiff *t, uint64_t idx, unsigned char *buf, 
 
     if (want > rawcap)
         return -1;
+    if (off > t->file_size || cnt > t->file_size - off)
+        return -1;                  /* chunk outside the file: corrupt directory */
     if (cnt == 0) {                 /* sparse tile: GDAL reads it as zeros */
         memset(buf, 0, want);
         return 0;

@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgcn10_host.so")
+LIB_PATH = os.environ.get("GCN10_HOST_LIB") or os.path.join(_HERE, "libgcn10_host.so")
 _lib = None
 
 HCS = ("p", "f", "g")               # src/cn.c:146
