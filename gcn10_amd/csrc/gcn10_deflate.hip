@@ -48,6 +48,8 @@ constexpr int kTileBytes = kTile * kTile;
 constexpr int kOutWords = 16416;                // 65 664 B: stored fallback (65 552 B) fits
 constexpr int kMaxStream = 2 + 2 * 5 + kTileBytes + 4;     // stored: header, 2 blocks, adler
 constexpr int kSlotAlign = 16;
+// streams up to this size are emitted by the two-workgroups-per-CU variant of pass C
+constexpr int kSmallStream = 12800;
 constexpr int kNumLit = 286;
 constexpr int kNumDist = 30;
 
@@ -102,6 +104,8 @@ struct Book {
     uint8_t pad[2];
     uint16_t dist_code[2];
     uint32_t header_bits;       // bit position after the block header (zlib header included)
+    uint32_t stream_bytes;      // size of the finished zlib stream (kMaxStream: stored fallback)
+    uint32_t slot;              // its offset in the arena, 0xffffffff if the arena is too small
     uint32_t header[64];        // the first header_bits bits of the stream
 };
 constexpr int kBookBytes = (int)sizeof(Book);
@@ -121,19 +125,16 @@ __device__ __forceinline__ void load_tile(const TileJob &job, const uint8_t *src
     const uint32_t y0 = ty * kTile + (uint32_t)(t >> 6);
     uint32_t *dst = reinterpret_cast<uint32_t *>(tile) + (t & 63);
     if ((tx + 1) * kTile <= job.W && (ty + 1) * kTile <= job.rows) {
-        // interior tile: 64 independent loads per thread, issued 16 at a time
+        // interior tile: 64 independent loads per thread, all in flight at once
         const uint8_t *p = src + (size_t)y0 * job.W + x;
         const size_t step = (size_t)job.W * 4;
-#pragma unroll 1
-        for (int i0 = 0; i0 < kTile / 4; i0 += 16) {
-            uint32_t v[16];
+        uint32_t v[kTile / 4];
 #pragma unroll
-            for (int i = 0; i < 16; i++)
-                v[i] = *reinterpret_cast<const u32_u *>(p + (size_t)(i0 + i) * step);
+        for (int i = 0; i < kTile / 4; i++)
+            v[i] = *reinterpret_cast<const u32_u *>(p + (size_t)i * step);
 #pragma unroll
-            for (int i = 0; i < 16; i++)
-                dst[((i0 + i) * 4 + (t >> 6)) * (kRowStride / 4)] = v[i];
-        }
+        for (int i = 0; i < kTile / 4; i++)
+            dst[(i * 4 + (t >> 6)) * (kRowStride / 4)] = v[i];
         return;
     }
     for (int i = 0; i < kTile / 4; i++) {
@@ -670,36 +671,92 @@ __global__ __launch_bounds__(kBuildThreads) void deflate_codes_kernel(const Tile
     for (int k = 0; k < 64; k++)
         book->header[k] = hdr[k];
     book->header_bits = bw.pos;
+
+    // ---- the stream's exact size follows from the statistics and the code lengths; its
+    // place in the arena is reserved here, so pass C neither measures the tile as a whole
+    // nor waits for an atomic ----
+    // (<= 65536 tokens of <= 15 + 5 + 15 + 6 bits: 32-bit arithmetic is enough)
+    uint32_t bits = bw.pos;
+#pragma unroll 1
+    for (int sy = 0; sy < kNumLit; sy++) {
+        const uint32_t f = hist[sy];
+        if (f)
+            bits += f * ((uint32_t)w.lit_len[sy] + (sy > 256 ? (uint32_t)kLenExtra[sy - 257] : 0u));
+    }
+    bits += n_near * (uint32_t)w.dist_len[0] + n_far * ((uint32_t)w.dist_len[15] + 6u);
+    uint32_t bytes = (bits + 7u) / 8u + 4u;
+    if (bytes > (uint32_t)kMaxStream - 64u)
+        bytes = (uint32_t)kMaxStream;           // stored fallback
+    const unsigned long long need = (bytes + (kSlotAlign - 1)) & ~(unsigned long long)(kSlotAlign - 1);
+    const unsigned long long slot = atomicAdd(job.cursor, need);
+    const bool fits = slot + need <= job.arena_cap;
+    book->stream_bytes = bytes;
+    book->slot = fits ? (uint32_t)slot : 0xffffffffu;
+    job.table[(size_t)tile * 2] = fits ? (uint32_t)slot : 0xffffffffu;
+    job.table[(size_t)tile * 2 + 1] = fits ? bytes : 0u;
 }
 
 // ------------------------------------------------------------------------
 // pass C: measure, place and emit; one workgroup per tile
 // ------------------------------------------------------------------------
+template <bool SMALL>
 struct SharedC {
+    static constexpr int kWords = SMALL ? kSmallStream / 4 + 16 : kOutWords;
     uint8_t tile[kTile * kRowStride];
-    uint32_t out[kOutWords];
+    uint32_t out[kWords];
     uint8_t lit_len[288];
     uint16_t lit_code[288];
-    uint32_t row_bits[kTile];
-    uint32_t scan[kTile];
-    uint32_t header_bits, total_bits, stream_bytes, use_stored;
-    unsigned long long slot;
+    uint32_t wave_sum[4];
 };
 
+// inclusive prefix sum over the 256 threads of the workgroup (4 waves of 64)
+__device__ __forceinline__ uint32_t block_scan(uint32_t v, uint32_t *wave_sum, int t)
+{
+    const int lane = t & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(v, off, 64);
+        if (lane >= off)
+            v += up;
+    }
+
+    if (lane == 63)
+        wave_sum[t >> 6] = v;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < (t >> 6); w++)
+        base += wave_sum[w];
+    return v + base;
+}
+
+// SMALL = true : streams of at most kSmallStream bytes, LDS for two workgroups per CU
+// SMALL = false: the others (noisy tiles, stored fallback), one workgroup per CU
+template <bool SMALL>
 __global__ __launch_bounds__(kTile) void deflate_emit_kernel(const TileJob job)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    SharedC &sh = *reinterpret_cast<SharedC *>(smem);
+    SharedC<SMALL> &sh = *reinterpret_cast<SharedC<SMALL> *>(smem);
     const int t = threadIdx.x;
+    const Book *book = reinterpret_cast<const Book *>(job.books + (size_t)blockIdx.x * kBookBytes);
+    const uint32_t stream_bytes = book->stream_bytes;
+    if ((stream_bytes <= (uint32_t)kSmallStream) != SMALL)
+        return;                                     // the other launch emits this tile
+    const uint32_t slot = book->slot;
+    if (slot == 0xffffffffu)
+        return;                                     // arena too small: the table says so
     const uint32_t tiles = job.across * job.down;
     const uint32_t raster = blockIdx.x / tiles;
     const uint32_t tix = blockIdx.x - raster * tiles;
     const uint32_t ty = tix / job.across, tx = tix - ty * job.across;
-    const Book *book = reinterpret_cast<const Book *>(job.books + (size_t)blockIdx.x * kBookBytes);
+    const uint32_t header_bits = book->header_bits;
+    const uint32_t adler = job.hist[(size_t)blockIdx.x * kHistWords + 290];
+    const bool stored = stream_bytes == (uint32_t)kMaxStream;
+    const uint32_t n_words = (stream_bytes + 3) / 4;
 
     load_tile(job, job.rasters[raster], tx, ty, sh.tile, t);
-    for (int i = t; i < kOutWords; i += kTile)
-        sh.out[i] = i < 64 ? book->header[i] : 0u;
+    // the output image: block header from pass B, zeros up to the stream's end
+    for (uint32_t i = t; i < n_words + 1; i += kTile)
+        sh.out[i] = (i < 64 && !stored) ? book->header[i] : 0u;
     for (int i = t; i < 288; i += kTile) {
         sh.lit_len[i] = book->lit_len[i];
         sh.lit_code[i] = book->lit_code[i];
@@ -711,47 +768,22 @@ __global__ __launch_bounds__(kTile) void deflate_emit_kernel(const TileJob job)
     cv.dist_len[1] = book->dist_len[1];
     cv.dist_code[0] = book->dist_code[0];
     cv.dist_code[1] = book->dist_code[1];
-    if (t == 0)
-        sh.header_bits = book->header_bits;
     __syncthreads();
 
-    RowMasks m;
-    row_masks(sh.tile, t, m);
-
-    // row bit lengths, inclusive prefix sum
-    {
+    uint8_t *o = reinterpret_cast<uint8_t *>(sh.out);
+    if (!stored) {
+        RowMasks m;
+        row_masks(sh.tile, t, m);
         const uint32_t bits = parse_row<kMeasure>(sh.tile, t, m, nullptr, nullptr, &cv, nullptr);
-        sh.row_bits[t] = bits;
-        sh.scan[t] = bits;
-    }
-    __syncthreads();
-    for (int off = 1; off < kTile; off <<= 1) {
-        const uint32_t v = t >= off ? sh.scan[t - off] : 0u;
-        __syncthreads();
-        sh.scan[t] += v;
-        __syncthreads();
-    }
-    if (t == 0) {
-        sh.total_bits = sh.header_bits + sh.scan[kTile - 1] + sh.lit_len[256];
-        const uint32_t bytes = (sh.total_bits + 7) / 8 + 4;
-        sh.use_stored = bytes > (uint32_t)kMaxStream - 64u;
-        sh.stream_bytes = sh.use_stored ? (uint32_t)kMaxStream : bytes;
-    }
-    __syncthreads();
-
-    if (!sh.use_stored) {
-        RowEmitter em{ sh.out, sh.header_bits + sh.scan[t] - sh.row_bits[t], 0ull, 0 };
+        const uint32_t incl = block_scan(bits, sh.wave_sum, t);
+        RowEmitter em{ sh.out, header_bits + incl - bits, 0ull, 0 };
         parse_row<kEmit>(sh.tile, t, m, nullptr, nullptr, &cv, &em);
         if (t == kTile - 1)
             em.put(sh.lit_code[256], sh.lit_len[256]);      // end of block
         em.finish();
     }
-    else {
+    else if (!SMALL) {
         // stored fallback: two blocks of 32768 bytes (LEN is 16 bit)
-        uint8_t *o = reinterpret_cast<uint8_t *>(sh.out);
-        for (int i = t; i < 64; i += kTile)
-            sh.out[i] = 0;
-        __syncthreads();
         if (t == 0) {
             o[0] = 0x78;
             o[1] = 0x01;
@@ -764,48 +796,27 @@ __global__ __launch_bounds__(kTile) void deflate_emit_kernel(const TileJob job)
                 h[4] = 0x7f;                    // NLEN
             }
         }
-        __syncthreads();
-        {
-            // row t = bytes 256 t .. 256 t + 255 of the tile; block b holds rows 128 b ..
-            uint8_t *dst = o + 2 + (t >> 7) * (5 + 32768) + 5 + (t & 127) * kTile;
-            const uint8_t *row = sh.tile + t * kRowStride;
-            for (int k = 0; k < kTile; k++)
-                dst[k] = row[k];
-        }
+        // row t = bytes 256 t .. 256 t + 255 of the tile; block b holds rows 128 b ..
+        uint8_t *dst = o + 2 + (t >> 7) * (5 + 32768) + 5 + (t & 127) * kTile;
+        const uint8_t *row = sh.tile + t * kRowStride;
+        for (int k = 0; k < kTile; k++)
+            dst[k] = row[k];
     }
     __syncthreads();
-
     if (t == 0) {
-        const uint32_t adler = job.hist[(size_t)blockIdx.x * kHistWords + 290];
-        uint8_t *o = reinterpret_cast<uint8_t *>(sh.out);
-        const uint32_t at = sh.stream_bytes - 4;
+        const uint32_t at = stream_bytes - 4;
         o[at] = (uint8_t)(adler >> 24);
         o[at + 1] = (uint8_t)(adler >> 16);
         o[at + 2] = (uint8_t)(adler >> 8);
         o[at + 3] = (uint8_t)adler;
-        const unsigned long long need = (sh.stream_bytes + (kSlotAlign - 1)) & ~(unsigned long long)(kSlotAlign - 1);
-        const unsigned long long slot = atomicAdd(job.cursor, need);
-        sh.slot = slot;
-        uint32_t *te = job.table + (size_t)blockIdx.x * 2;
-        if (slot + need <= job.arena_cap) {
-            te[0] = (uint32_t)slot;
-            te[1] = sh.stream_bytes;
-        }
-        else {
-            te[0] = 0xffffffffu;        // arena too small: reported by the host
-            te[1] = 0;
-        }
     }
     __syncthreads();
     {
-        const unsigned long long slot = sh.slot;
-        const uint32_t nvec = (sh.stream_bytes + 15) / 16;
-        if (slot + (unsigned long long)nvec * 16 <= job.arena_cap) {
-            u32x4 *dst = reinterpret_cast<u32x4 *>(job.arena + slot);
-            const u32x4 *srcv = reinterpret_cast<const u32x4 *>(sh.out);
-            for (uint32_t i = t; i < nvec; i += kTile)
-                dst[i] = srcv[i];
-        }
+        const uint32_t nvec = (stream_bytes + 15) / 16;
+        u32x4 *dst = reinterpret_cast<u32x4 *>(job.arena + slot);
+        const u32x4 *srcv = reinterpret_cast<const u32x4 *>(sh.out);
+        for (uint32_t i = t; i < nvec; i += kTile)
+            dst[i] = srcv[i];
     }
 }
 
@@ -866,7 +877,8 @@ int gcn10_gpu_deflate_strip(gcn10_gpu_ctx *ctx, const uint8_t *const *rasters_de
     job.hist = reinterpret_cast<uint32_t *>(ctx->deflate_ws);
     job.books = reinterpret_cast<uint8_t *>(ctx->deflate_ws) + (size_t)nblocks * kHistWords * 4;
 
-    static_assert(sizeof(SharedC) <= 160 * 1024, "tile + output image must fit the CU's 160 KiB of LDS");
+    static_assert(sizeof(SharedC<false>) <= 160 * 1024, "tile + output image must fit the CU's 160 KiB of LDS");
+    static_assert(sizeof(SharedC<true>) <= 80 * 1024, "two small-stream workgroups must fit one CU");
     static_assert(sizeof(Work) * kBuildThreads <= 160 * 1024, "code construction slices must fit LDS");
     static_assert(kBookBytes % 4 == 0, "code books are dword aligned");
     if (!ctx->deflate_ready) {
@@ -876,8 +888,10 @@ int gcn10_gpu_deflate_strip(gcn10_gpu_ctx *ctx, const uint8_t *const *rasters_de
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(deflate_codes_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(sizeof(Work) * kBuildThreads)));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(deflate_emit_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SharedC)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(deflate_emit_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SharedC<true>)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(deflate_emit_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SharedC<false>)));
         ctx->deflate_ready = true;
     }
     hipStream_t s = as_stream(ctx, stream);
@@ -885,7 +899,10 @@ int gcn10_gpu_deflate_strip(gcn10_gpu_ctx *ctx, const uint8_t *const *rasters_de
     hipLaunchKernelGGL(deflate_stats_kernel, dim3((uint32_t)nblocks), dim3(kTile), sizeof(SharedA), s, job);
     hipLaunchKernelGGL(deflate_codes_kernel, dim3(((uint32_t)nblocks + kBuildThreads - 1) / kBuildThreads),
                        dim3(kBuildThreads), sizeof(Work) * kBuildThreads, s, job);
-    hipLaunchKernelGGL(deflate_emit_kernel, dim3((uint32_t)nblocks), dim3(kTile), sizeof(SharedC), s, job);
+    hipLaunchKernelGGL(deflate_emit_kernel<true>, dim3((uint32_t)nblocks), dim3(kTile), sizeof(SharedC<true>), s,
+                       job);
+    hipLaunchKernelGGL(deflate_emit_kernel<false>, dim3((uint32_t)nblocks), dim3(kTile), sizeof(SharedC<false>),
+                       s, job);
     HIP_TRY(hipGetLastError());
     return GCN10_OK;
 }

@@ -107,7 +107,8 @@ def test_all_65536_pairs_both_kernels(eng9, tables):
 # ---- fused block path -----------------------------------------------------
 
 SHAPES = [(1, 1), (1, 15), (1, 16), (1, 17), (17, 1), (5, 3), (3, 5000), (64, 64), (257, 131),
-          (300, 300), (64, 1040), (33, 4099), (130, 1024), (9, 36001 // 9)]
+          (300, 300), (64, 1040), (33, 4099), (130, 1024), (9, 36001 // 9),
+          (70, 36001)]        # the real block width: rows not 16-byte aligned
 
 
 @pytest.mark.parametrize("shape", SHAPES)

@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--pattern", default="patches")
     ap.add_argument("--deflate-level", type=int, default=0)
     ap.add_argument("--gpu-deflate", type=int, default=1)
+    ap.add_argument("--esa-compression", type=int, default=1,
+                    help="TIFF compression of the landcover input: 1 none, 8 DEFLATE (like the ESA COGs), 5 LZW")
     a = ap.parse_args()
     wd = a.workdir
     shutil.rmtree(wd, ignore_errors=True)
@@ -49,7 +51,7 @@ def main():
     esa = np.concatenate([esa1] * nb, axis=1) if nb > 1 else esa1
     del esa1
     tiffutil.write_tiff(os.path.join(wd, "esa.tif"), esa, gt=[0.0, px, 0.0, 3.0, 0.0, -px],
-                        compression=1, tile=(1024, 1024), bigtiff=esa.size > 3 * 2**30)
+                        compression=a.esa_compression, tile=(1024, 1024), bigtiff=esa.size > 3 * 2**30)
     del esa
     hs = coarse1.shape[0]
     soil = np.concatenate([coarse1] * nb, axis=1) if nb > 1 else coarse1
@@ -63,7 +65,7 @@ def main():
                 % (wd, wd, wd, os.path.join(ROOT, "tests", "golden", "lookups"), wd, a.strip_rows,
                    a.deflate_level, a.gpu_deflate))
     build_s = time.time() - t0
-    res = {"size": size, "blocks": nb, "strip_rows": a.strip_rows, "gpus": a.gpus, "pattern": a.pattern, "gpu_deflate": a.gpu_deflate,
+    res = {"size": size, "blocks": nb, "strip_rows": a.strip_rows, "gpus": a.gpus, "pattern": a.pattern, "gpu_deflate": a.gpu_deflate, "esa_compression": a.esa_compression,
            "world_build_seconds": round(build_s, 1), "modes": {}}
     for mode in a.modes.split(","):
         env = dict(os.environ)
