@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--pattern", default="patches")
     ap.add_argument("--deflate-level", type=int, default=0)
     ap.add_argument("--gpu-deflate", type=int, default=1)
+    ap.add_argument("--real-vrt-pixel", action="store_true",
+                    help="use the shipped VRT's pixel size 8.3333333333330430e-05: 3-degree blocks become "
+                         "36001 px wide (SURVEY.md section 7), rows are not 16-byte aligned")
     ap.add_argument("--esa-compression", type=int, default=1,
                     help="TIFF compression of the landcover input: 1 none, 8 DEFLATE (like the ESA COGs), 5 LZW")
     a = ap.parse_args()
@@ -44,6 +47,8 @@ def main():
     os.makedirs(wd)
     size, nb = a.size, a.blocks
     px = 3.0 / size
+    if a.real_vrt_pixel:
+        size, px = 36001, 8.3333333333330430e-05
     t0 = time.time()
     # landcover: nb blocks side by side (lon 0..3*nb, lat 0..3), written tile-wise without
     # holding more than one block in memory
