@@ -140,7 +140,12 @@ def main():
 
     from gcn10_amd import gpu, host
     grp = shard.Group()                     # nccl (= RCCL) when WORLD_SIZE > 1, nothing otherwise
-    eng = gpu.Engine(local_rank)
+    n_dev = gpu.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if local_rank >= n_dev and os.environ.get("GCN10_DIST_BACKEND") != "gloo":
+        raise SystemExit("rank %d has no GPU (only %d visible)" % (local_rank, n_dev))
+    eng = gpu.Engine(local_rank % n_dev)      # modulo only matters for the gloo rehearsal on one GPU
     info = eng.device_info()
     tables = host.load_all_lookup_tables(os.path.join(ROOT, "tests", "golden", "lookups"))
     eng.set_tables(tables)
@@ -259,7 +264,9 @@ def main():
                        "device": info["name"], "cus": info["cus"]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic_from_profiles(args.workload),
+                         # the committed PMC passes were taken at the default shape only
+                         "traffic": traffic_from_profiles(args.workload)
+                         if (size == 36000 and strip == size and args.pattern == "iid") else None,
                          "kernel": kname, "algorithmic_bytes_per_launch": int(alg_bytes),
                          "avg_launch_ms": round(avg_launch_s * 1e3, 4),
                          "min_launch_ms": round(float(np.min(kernel_ms)) / launches, 4)},

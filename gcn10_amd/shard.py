@@ -37,7 +37,9 @@ class Group:
         if self.world > 1:
             import torch
             import torch.distributed as dist
-            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+            # GCN10_DIST_BACKEND=gloo lets several ranks rehearse on one GPU (tests)
+            backend = backend or os.environ.get("GCN10_DIST_BACKEND") or \
+                ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
                 idx = self.local_rank if device_index is None else device_index
                 torch.cuda.set_device(idx)
