@@ -314,7 +314,7 @@ __device__ __forceinline__ void issue_trip(const StripParams &p, uint32_t chunk,
     }
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
-#if defined(GCN10_DIAG) && GCN10_DIAG == 2
+#if defined(GCN10_DIAG) && (GCN10_DIAG == 2 || GCN10_DIAG == 3)
         tr.c16[u] = u32x4{ row[u], tr.x0[u], 0u, 0u } & 0x11111111u;    // timing-only build: no soil load
 #else
         const size_t off = tr.fast[u] ? (size_t)row[u] * p.hx_stride + tr.x0[u] : (size_t)0;
@@ -370,7 +370,7 @@ __device__ __forceinline__ void finish_trip(const StripParams &p, const uint8_t 
             }
             else {
                 u32x4 v;
-#if defined(GCN10_DIAG) && GCN10_DIAG == 1
+#if defined(GCN10_DIAG) && (GCN10_DIAG == 1 || GCN10_DIAG == 3)
                 v = tr.e16[u] ^ tr.c16[u];          // timing-only build: no table lookup
 #else
 #pragma unroll

@@ -200,3 +200,50 @@ def test_outer_launcher_ranks_take_round_robin_shares(tmp_path):
     assert "process 0 of 2: 2 of 3 blocks" in log0 and "process 1 of 2: 1 of 3 blocks" in log1
     assert "processing block 101" in log0 and "processing block 103" in log0 and "processing block 102" in log1
     assert len(os.listdir(tmp_path / "cn_rasters_drained")) == 27
+
+
+@pytest.mark.gpu
+def test_vrt_landcover_with_local_tile_mirror(tmp_path, tables):
+    """esa_data_path is a VRT of /vsicurl/ tiles, as in the reference's src/test/config.txt; offline
+    its sources resolve to esa_tile_dir.  Two tiles side by side, a block straddling both."""
+    rng = np.random.default_rng(31)
+    esa = rng.choice(ESA_NASTY, size=(2000, 3000)).astype(np.uint8)
+    esa[esa == 0] = 10                                  # ComplexSource NODATA=0 stays transparent
+    soil = rng.choice(HSG_NASTY, size=(82, 122)).astype(np.uint8)
+    (tmp_path / "tiles").mkdir()
+    tiffutil.write_tiff(str(tmp_path / "tiles" / "T_W.tif"), esa[:, :1500], compression=8, tile=(512, 512))
+    tiffutil.write_tiff(str(tmp_path / "tiles" / "T_E.tif"), esa[:, 1500:], compression=5, tile=(256, 256))
+    src = ""
+    for name, dx in (("T_W.tif", 0), ("T_E.tif", 1500)):
+        src += ('<ComplexSource resampling="nearest"><SourceFilename relativeToVRT="0">/vsicurl/https://example.invalid/'
+                'map/%s</SourceFilename><SourceBand>1</SourceBand><SrcRect xOff="0" yOff="0" xSize="1500" ySize="2000" />'
+                '<DstRect xOff="%d" yOff="0" xSize="1500" ySize="2000" /><NODATA>0</NODATA></ComplexSource>\n' % (name, dx))
+    (tmp_path / "esa.vrt").write_text(
+        '<VRTDataset rasterXSize="3000" rasterYSize="2000">\n<GeoTransform> %r, %r, 0.0, %r, 0.0, %r</GeoTransform>\n'
+        '<VRTRasterBand dataType="Byte" band="1"><NoDataValue>0</NoDataValue>\n%s</VRTRasterBand></VRTDataset>\n'
+        % (ESA_GT[0], ESA_GT[1], ESA_GT[3], ESA_GT[5], src))
+    tiffutil.write_tiff(str(tmp_path / "soil.tif"), soil, gt=SOIL_GT, compression=5, rows_per_strip=8)
+    tiffutil.write_block_shapefile(str(tmp_path / "blocks"), [(7, 11.0, 48.5, 12.0, 49.5)])   # columns 1000..2000
+    (tmp_path / "config.txt").write_text(
+        "hysogs_data_path=%s\nesa_data_path=%s\nblocks_shp_path=%s\nlookup_table_path=%s\nlog_dir=%s\n"
+        "esa_tile_dir=%s\nstrip_rows=512\n" % (tmp_path / "soil.tif", tmp_path / "esa.vrt", tmp_path / "blocks.shp",
+                                               LOOKUPS, tmp_path / "logs", tmp_path / "tiles"))
+    out = _run(tmp_path, "-c", "config.txt")
+    assert out.returncode == 0, out.stderr[-2000:]
+    bbox = [11.0, 48.5, 12.0, 49.5]
+    xo, yo, W, H, gt = oc.window(ESA_GT, 3000, 2000, bbox)
+    sxo, syo, hsx, hsy, sgt = oc.window(SOIL_GT, soil.shape[1], soil.shape[0], bbox)
+    assert xo < 1500 < xo + W                           # the window spans both tiles
+    want = oc.process_block_mem(esa[yo:yo + H, xo:xo + W], gt, soil[syo:syo + hsy, sxo:sxo + hsx], sgt, tables)
+    for r in (0, 4, 8, 9, 13, 17):
+        c, k = divmod(r, 9)
+        p = tmp_path / ("cn_rasters_%s" % CONDS[c]) / ("cn_%s_%s_7.tif" % (HCS[k // 3], ARCS[k % 3]))
+        im = Image.open(str(p))
+        assert np.array_equal(np.array(im), want[r])
+        assert 4326 in im.tag_v2[34735]                 # VRT input: WGS84 default GeoKeys
+    # without the mirror the landcover cannot be read: the block is skipped with the reference's message
+    cfg = (tmp_path / "config.txt").read_text().replace("esa_tile_dir=%s\n" % (tmp_path / "tiles"), "")
+    (tmp_path / "config.txt").write_text(cfg)
+    out = _run(tmp_path, "-c", "config.txt", "-o")
+    assert out.returncode == 0
+    assert "esa load failed for block 7" in (tmp_path / "logs" / "rank_0.log").read_text()
