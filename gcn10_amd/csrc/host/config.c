@@ -78,6 +78,8 @@ int gcn10_config_parse(const char *path, gcn10_config *cfg, char *err, size_t er
             rc = set_str(&cfg->esa_tile_dir, val);
         else if (!strcmp(key, "gpus"))
             cfg->gpus = atoi(val);
+        else if (!strcmp(key, "workers_per_gpu"))
+            cfg->workers_per_gpu = atoi(val);
         else if (!strcmp(key, "strip_rows"))
             cfg->strip_rows = atoi(val);
         else if (!strcmp(key, "io_threads"))

@@ -82,7 +82,8 @@ class Config(C.Structure):
     """``gcn10_config`` of include/gcn10_host.h."""
     _fields_ = [("hysogs_data_path", C.c_char_p), ("esa_data_path", C.c_char_p),
                 ("blocks_shp_path", C.c_char_p), ("lookup_table_path", C.c_char_p),
-                ("log_dir", C.c_char_p), ("gpus", C.c_int), ("strip_rows", C.c_int),
+                ("log_dir", C.c_char_p), ("gpus", C.c_int), ("workers_per_gpu", C.c_int),
+                ("strip_rows", C.c_int),
                 ("io_threads", C.c_int), ("deflate_level", C.c_int), ("esa_tile_dir", C.c_char_p),
                 ("gpu_deflate", C.c_int)]
 

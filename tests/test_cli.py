@@ -36,7 +36,7 @@ def _world(tmp_path, seed=5, extra_cfg=""):
     tiffutil.write_block_shapefile(str(tmp_path / "blocks"), BLOCKS)
     (tmp_path / "config.txt").write_text(
         "# test config\nhysogs_data_path=%s\nesa_data_path=%s\nblocks_shp_path=%s\n"
-        "lookup_table_path=%s\nlog_dir=%s\nstrip_rows=256\nio_threads=4\n%s"
+        "lookup_table_path=%s\nlog_dir=%s\nstrip_rows=256\nio_threads=4\nworkers_per_gpu=1\n%s"
         % (tmp_path / "soil_lzw.tif", tmp_path / "esa.tif", tmp_path / "blocks.shp", LOOKUPS, tmp_path / "logs",
            extra_cfg))
     return esa, soil
@@ -140,6 +140,19 @@ def test_overwrite_rule_and_shapefile_mode(tmp_path, tables):
     log = (tmp_path / "logs" / "rank_0.log").read_text()
     assert "processing 4 blocks from shapefile" in log
     assert (tmp_path / "cn_rasters_undrained" / "cn_g_iii_103.tif").exists()
+
+
+@pytest.mark.gpu
+def test_default_is_two_workers_per_gpu(tmp_path):
+    _world(tmp_path, seed=23)
+    cfg = (tmp_path / "config.txt").read_text().replace("workers_per_gpu=1\n", "")
+    (tmp_path / "config.txt").write_text(cfg)
+    out = _run(tmp_path, "-c", "config.txt", "--gpus", "1")
+    assert out.returncode == 0, out.stderr[-2000:]
+    log0 = (tmp_path / "logs" / "rank_0.log").read_text()
+    assert "starting processing with 2 gpu workers" in log0 and "processed 4 blocks on 2 ranks" in log0
+    assert (tmp_path / "logs" / "rank_1.log").exists()
+    assert len(os.listdir(tmp_path / "cn_rasters_drained")) == 27
 
 
 @pytest.mark.gpu

@@ -33,9 +33,9 @@ def test_config_reference_file_shape(tmp_path):
 def test_config_optional_keys_and_errors(tmp_path):
     p = tmp_path / "c.txt"
     base = "hysogs_data_path=a\nesa_data_path=b\nblocks_shp_path=c\nlookup_table_path=d\nlog_dir=e\n"
-    p.write_text(base + "gpus=4\nstrip_rows=512\nio_threads=3\ndeflate_level=1\nesa_tile_dir=/x\ngpu_deflate=0\n")
+    p.write_text(base + "workers_per_gpu=3\ngpus=4\nstrip_rows=512\nio_threads=3\ndeflate_level=1\nesa_tile_dir=/x\ngpu_deflate=0\n")
     c = host.parse_config(str(p))
-    assert c["gpu_deflate"] == 0
+    assert c["gpu_deflate"] == 0 and c["workers_per_gpu"] == 3
     assert (c["gpus"], c["strip_rows"], c["io_threads"], c["deflate_level"], c["esa_tile_dir"]) == \
         (4, 512, 3, 1, "/x")
     p.write_text("hysogs_data_path=a\nesa_data_path=b\n")
