@@ -492,7 +492,7 @@ __global__ __launch_bounds__(kThreads) void expand_x_codes(const uint8_t *coarse
     // coarse row is ~1.4 KB), one 16-byte store
     const uint32_t x = (blockIdx.x * blockDim.x + threadIdx.x) * 16u;
     const uint32_t r = blockIdx.y;
-    if (x >= hx_stride)
+    if (x >= hx_stride || r >= hsy)
         return;
     const uint8_t *row = coarse + (size_t)r * hsx;
     const uint8_t pad = (uint8_t)(kInvalidPlane | (kInvalidPlane << 4));

@@ -142,7 +142,7 @@ static int parse_vrt(struct gcn10_raster *r, const char *path, const char *tile_
         const char *close_tag, *e, *fn, *fn_txt, *fn_end, *rect, *rect_end;
         bool complex_src;
         struct vrt_source src;
-        int relative = 0, dummy;
+        int relative = 0;
 
         if (!s)
             break;
@@ -234,7 +234,6 @@ static int parse_vrt(struct gcn10_raster *r, const char *path, const char *tile_
             if (nd && nd < e)
                 src.nodata = (int)strtod(nd + 8, NULL);
         }
-        (void)dummy;
         if (src.w > 0 && src.h > 0) {
             if (r->n_src == cap) {
                 struct vrt_source *g = realloc(r->src, (size_t)(cap ? cap * 2 : 64) * sizeof *g);
