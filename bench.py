@@ -181,13 +181,17 @@ def main():
                 eng.event_record(ev[i_timed][1])
             return
         eng.prepare_tile(d_coarse.ptr, hs, hs, d_ci.ptr, size)
-        if i_timed is not None:
+        whole = strip >= size
+        if i_timed is not None and not whole:
             eng.event_record(ev[i_timed][0])
         for y0 in range(0, size, strip):
             rows = min(strip, size - y0)
             ptrs = [p + y0 * size if p else None for p in outs]
+            if i_timed is not None and whole:
+                # events carried by the dispatch itself: the kernel's own duration
+                eng.time_next_strip(ev[i_timed][0], ev[i_timed][1])
             eng.cn_strip(d_esa.at(y0 * size), size, rows, d_cj.at(4 * y0), cond_mask, table_mask, ptrs)
-        if i_timed is not None:
+        if i_timed is not None and not whole:
             eng.event_record(ev[i_timed][1])
 
     def full_sync():

@@ -24,6 +24,7 @@
 // DRAM traffic against ~20 VALU ops and 2 ds_read_b128 per pixel.
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -1264,7 +1265,17 @@ int gcn10_gpu_cn_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, int rows,
         strip_kernel_t fn = pick_strip_kernel(single, cond_mask, all, ilp, nt, pf);
         if (!fn)
             return fail(GCN10_E_INVAL, "gcn10_gpu_cn_strip: no kernel for ilp=%d", ilp);
-        hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), 0, s, p);
+        if (ctx->time_start && ctx->time_stop) {
+            // events attached to the dispatch itself: they bracket the kernel, not the
+            // command-processor gaps around separately recorded events
+            void *args[] = { &p };
+            HIP_TRY(hipExtLaunchKernel(reinterpret_cast<const void *>(fn), dim3(grid), dim3(kThreads), args, 0,
+                                       s, ctx->time_start, ctx->time_stop, 0));
+            ctx->time_start = ctx->time_stop = nullptr;
+        }
+        else {
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), 0, s, p);
+        }
         // the instantiation's name as rocprofv3 prints it: <KIND, COND_MASK, ALL_TABLES, ILP, NT, PF>
         snprintf(ctx->kernel_name, sizeof ctx->kernel_name, "cn_strip_kernel<%d, %u, %s, %d, %s, %s>",
                  single ? 1 : 0, cond_mask, (all || single) ? "true" : "false", ilp, nt ? "true" : "false",
@@ -1305,6 +1316,15 @@ int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value)
         ctx->prefetch = value;
     else
         return fail(GCN10_E_INVAL, "gcn10_gpu_set_option: unknown option or bad value: %s=%d", name, value);
+    return GCN10_OK;
+}
+
+int gcn10_gpu_time_next_strip(gcn10_gpu_ctx *ctx, gcn10_event_t start, gcn10_event_t stop)
+{
+    if (!ctx || !start || !stop)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_time_next_strip: null argument");
+    ctx->time_start = reinterpret_cast<hipEvent_t>(start);
+    ctx->time_stop = reinterpret_cast<hipEvent_t>(stop);
     return GCN10_OK;
 }
 

@@ -50,6 +50,7 @@ struct gcn10_gpu_ctx {
     int xcd_slabs = 1;
     int prefetch = -1;      // loads of the next trip issued before the current one is consumed:
                             // -1 = per kernel default (on for all-tables, off for single-table)
+    hipEvent_t time_start = nullptr, time_stop = nullptr;  // one-shot: bracket the next strip kernel
     bool deflate_ready = false;     // LDS attributes of the tile encoder set on this device
     void *deflate_ws = nullptr;     // per-tile statistics + code books of the tile encoder
     size_t deflate_ws_cap = 0;

@@ -38,7 +38,7 @@ ABI_SYMBOLS = (
     "gcn10_gpu_set_tables", "gcn10_gpu_resample", "gcn10_gpu_modify_hysogs_data",
     "gcn10_gpu_calculate_cn", "gcn10_gpu_prepare_tile", "gcn10_gpu_cn_strip",
     "gcn10_gpu_strip_algorithmic_bytes", "gcn10_gpu_last_kernel_name", "gcn10_gpu_set_option",
-    "gcn10_gpu_deflate_arena_bound", "gcn10_gpu_deflate_strip",
+    "gcn10_gpu_deflate_arena_bound", "gcn10_gpu_deflate_strip", "gcn10_gpu_time_next_strip",
 )
 
 
@@ -90,6 +90,7 @@ def lib():
             "gcn10_gpu_strip_algorithmic_bytes": (sz, [i, i, i, i, u, u]),
             "gcn10_gpu_last_kernel_name": (C.c_char_p, [vp]),
             "gcn10_gpu_set_option": (i, [vp, C.c_char_p, i]),
+            "gcn10_gpu_time_next_strip": (i, [vp, vp, vp]),
             "gcn10_gpu_deflate_arena_bound": (sz, [i, i, i]),
             "gcn10_gpu_deflate_strip": (i, [vp, vp, i, i, i, vp, sz, vp, vp, vp]),
         }
@@ -245,6 +246,9 @@ class Engine:
     def set_option(self, name: str, value: int):
         self._chk(lib().gcn10_gpu_set_option(self._ctx, name.encode(), int(value)),
                   "gcn10_gpu_set_option")
+
+    def time_next_strip(self, e0, e1):
+        self._chk(lib().gcn10_gpu_time_next_strip(self._ctx, e0, e1), "gcn10_gpu_time_next_strip")
 
     def last_kernel_name(self) -> str:
         return lib().gcn10_gpu_last_kernel_name(self._ctx).decode()

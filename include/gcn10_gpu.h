@@ -188,6 +188,11 @@ int gcn10_gpu_deflate_strip(gcn10_gpu_ctx *ctx, const uint8_t *const *rasters_de
  * "ilp1" (1|2|4), "nontemporal" (0|1), "xcd_slabs" (0|1), "prefetch" (-1 = per-kernel default | 0 | 1). */
 int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value);
 
+/* Measurement: the next gcn10_gpu_cn_strip launch records `start` / `stop` as part of
+ * the kernel dispatch itself (hipExtLaunchKernel), so gcn10_gpu_event_elapsed_ms gives
+ * the kernel's own duration -- the figure rocprofv3 --kernel-trace reports. One shot. */
+int gcn10_gpu_time_next_strip(gcn10_gpu_ctx *ctx, gcn10_event_t start, gcn10_event_t stop);
+
 /* Name of the variant of the strip kernel the last cn_strip call launched
  * (for profiles and bench records). */
 const char *gcn10_gpu_last_kernel_name(gcn10_gpu_ctx *ctx);
