@@ -268,42 +268,38 @@ __device__ __forceinline__ void issue_trip(const StripParams &p, uint32_t chunk,
                                            uint32_t wave_off, Trip<ILP> &tr)
 {
     uint32_t row[ILP];
-    // ---- addresses.  The coarse row of a wave's first pixel (and of the next
-    // raster row) comes through the scalar cache, so the soil load below does
-    // not wait behind a vector load of cj ----
+    // ---- addresses.  The coarse rows of a wave's first pixel and of the next raster
+    // row come through the scalar cache (all scalar loads of the trip first, one wait),
+    // so the soil load below does not wait behind a vector load of cj ----
+    uint32_t wave_base[ILP], yb[ILP], xb[ILP], r0[ILP], r1[ILP];
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
-        const uint32_t wave_base = __builtin_amdgcn_readfirstlane(
-            (chunk * ILP + u) * (uint32_t)kChunk + wave_off);
-        tr.i0[u] = wave_base + lane_off;
+        wave_base[u] = __builtin_amdgcn_readfirstlane((chunk * ILP + u) * (uint32_t)kChunk + wave_off);
+        // past the strip's end the wave only needs valid addresses: row 0
+        const uint32_t wb = wave_base[u] < p.npix ? wave_base[u] : 0u;
+        yb[u] = wb / p.W;
+        xb[u] = wb - yb[u] * p.W;
+        r0[u] = (uint32_t)scalar_load_i32(p.cj, yb[u]);
+        r1[u] = (uint32_t)scalar_load_i32(p.cj, yb[u] + 1u < p.rows ? yb[u] + 1u : yb[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < ILP; u++) {
+        tr.i0[u] = wave_base[u] + lane_off;
         tr.live[u] = tr.i0[u] < p.npix;
-        tr.fast[u] = false;
-        tr.y[u] = tr.x0[u] = 0;
-        row[u] = 0;
-        if (wave_base < p.npix) {           // wave-uniform
-            const uint32_t yb = wave_base / p.W;
-            const uint32_t xb = wave_base - yb * p.W;
-            const uint32_t yn = yb + 1u < p.rows ? yb + 1u : yb;
-            const uint32_t r0 = clamp_row(p, scalar_load_i32(p.cj, yb));
-            const uint32_t r1 = clamp_row(p, scalar_load_i32(p.cj, yn));
-            uint32_t xx = xb + lane_off, yy = yb;
-            row[u] = r0;
-            if (xx >= p.W) {
-                xx -= p.W;
-                yy = yb + 1u;
-                row[u] = r1;
-                if (xx >= p.W) {            // rows narrower than a wave's span
-                    const uint32_t q = xx / p.W;
-                    yy += q;
-                    xx -= q * p.W;
-                    if (tr.live[u])
-                        row[u] = soil_row(p, yy);
-                }
-            }
-            tr.y[u] = yy;
-            tr.x0[u] = xx;
-            tr.fast[u] = tr.live[u] && tr.i0[u] + kPxPerLane <= p.npix && xx + kPxPerLane <= p.W;
+        uint32_t xx = xb[u] + lane_off;
+        const bool wrap = xx >= p.W;
+        uint32_t yy = wrap ? yb[u] + 1u : yb[u];
+        xx = wrap ? xx - p.W : xx;
+        row[u] = clamp_row(p, (int32_t)(wrap ? r1[u] : r0[u]));
+        if (xx >= p.W) {                    // rows narrower than a wave's span
+            const uint32_t q = xx / p.W;
+            yy += q;
+            xx -= q * p.W;
+            row[u] = tr.live[u] ? soil_row(p, yy) : 0u;
         }
+        tr.y[u] = yy;
+        tr.x0[u] = xx;
+        tr.fast[u] = tr.live[u] && tr.i0[u] + kPxPerLane <= p.npix && xx + kPxPerLane <= p.W;
     }
     // ---- loads: a lane without a fast-path chunk reads the strip's first 16 bytes
     // instead (the host guarantees npix >= 16 for this kernel), so no exec-masked
