@@ -697,6 +697,422 @@ __global__ __launch_bounds__(kBuildThreads) void deflate_codes_kernel(const Tile
 }
 
 // ------------------------------------------------------------------------
+// pass B, wave-parallel form: one WAVE per tile.  Same outputs as the per-thread
+// kernel above (which stays as the cross-check, option "deflate_codes" = 0): sort by
+// a bitonic network in LDS, the two-queue Huffman merge on register-resident queues
+// (v_readlane / v_writelane with wave-uniform indices), leaf depths by parallel
+// parent walks, lengths by rank, canonical codes by ballots per length, the
+// code-length run-length coding by one lane per run with a prefix sum of run sizes.
+// ------------------------------------------------------------------------
+constexpr int kWavesPerBlock = 4;
+struct WaveWork {
+    uint32_t keys[256];         // (freq << 9 | symbol), sorted ascending; <= kMaxLive live
+    uint16_t parent[2 * kMaxLive];
+    uint8_t len[320];           // code length per lit/len symbol (0..285), then per distance code
+    uint32_t hdr[68];           // 2048 header bits at most, + the word an OR may spill into
+};
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t uni(uint32_t v)
+{
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+// element idx (wave-uniform) of an array spread over three registers (lane + 64 k)
+__device__ __forceinline__ uint32_t lane_array_get(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t idx)
+{
+    const uint32_t lane = idx & 63u;
+    const uint32_t which = idx >> 6;
+    return which == 0 ? __builtin_amdgcn_readlane(r0, lane)
+                      : which == 1 ? __builtin_amdgcn_readlane(r1, lane) : __builtin_amdgcn_readlane(r2, lane);
+}
+
+__device__ __forceinline__ void lane_array_set(uint32_t &r0, uint32_t &r1, uint32_t &r2, uint32_t idx,
+                                               uint32_t v, int my_lane)
+{
+    const bool mine = (uint32_t)my_lane == (idx & 63u);
+    const uint32_t which = idx >> 6;
+    if (which == 0)
+        r0 = mine ? v : r0;
+    else if (which == 1)
+        r1 = mine ? v : r1;
+    else
+        r2 = mine ? v : r2;
+}
+
+// bits and tokens of one run of `n` equal code lengths `v` (RFC 1951 3.2.7), in the fixed
+// code of the code-length alphabet; with a writer the tokens are emitted as well
+__device__ __forceinline__ uint32_t rle_run(int v, int n, uint32_t *out, uint32_t pos)
+{
+    const int vbits = v >= 10 && v < 16 ? 5 : 4;
+    uint32_t bits = 0;
+    auto put = [&](uint32_t value, int nbits) {
+        if (out) {
+            const uint32_t at = pos + bits;
+            const uint32_t w = at >> 5, sh = at & 31;
+            atomicOr(&out[w], value << sh);
+            if (sh + nbits > 32)
+                atomicOr(&out[w + 1], value >> (32 - sh));
+        }
+        bits += nbits;
+    };
+    int left = n;
+    if (v == 0) {
+        while (left >= 11) {
+            const int r = left > 138 ? 138 : left;
+            put(cl_code_of(18), 4);
+            put((uint32_t)(r - 11), 7);
+            left -= r;
+        }
+        if (left >= 3) {
+            put(cl_code_of(17), 4);
+            put((uint32_t)(left - 3), 3);
+            left = 0;
+        }
+    }
+    else {
+        put(cl_code_of(v), vbits);
+        left--;
+        while (left >= 3) {
+            const int r = left > 6 ? 6 : left;
+            put(cl_code_of(16), 4);
+            put((uint32_t)(r - 3), 2);
+            left -= r;
+        }
+    }
+    while (left-- > 0)
+        put(cl_code_of(v), vbits);
+    return bits;
+}
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel(const TileJob job)
+{
+    __shared__ __attribute__((aligned(16))) WaveWork work[kWavesPerBlock];
+    const int lane = threadIdx.x & 63;
+    const uint32_t tile = uni(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (tile >= job.n_tiles)
+        return;
+    WaveWork &w = work[threadIdx.x >> 6];
+    const uint32_t *hist = job.hist + (size_t)tile * kHistWords;
+    Book *book = reinterpret_cast<Book *>(job.books + (size_t)tile * kBookBytes);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    // ---- statistics: lane holds symbols lane + 64 c ----
+    uint32_t h[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const int s = c * 64 + lane;
+        h[c] = s < kNumLit ? hist[s] : 0u;
+        w.len[s] = 0;
+    }
+    const uint32_t n_near = hist[288], n_far = hist[289];
+
+    // ---- live symbols, compacted in symbol order ----
+    uint32_t m = 0;
+    uint32_t pos[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const bool live = h[c] != 0;
+        const unsigned long long mask = __ballot(live);
+        pos[c] = m + (uint32_t)__popcll(mask & lt_mask);
+        if (live && pos[c] < 256u)
+            w.keys[pos[c]] = (h[c] << 9) | (uint32_t)(c * 64 + lane);
+        m += (uint32_t)__popcll(mask);
+    }
+    m = uni(m);
+
+    uint32_t count[17];
+#pragma unroll
+    for (int i = 0; i <= 16; i++)
+        count[i] = 0;
+
+    if (m > (uint32_t)kMaxLive) {
+        // flat code: 2^L - m symbols of L-1 bits, the others L bits
+        uint32_t L = 1;
+        while ((1u << L) < m)
+            L++;
+        const uint32_t n_short = (1u << L) - m;
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+            if (h[c])
+                w.len[c * 64 + lane] = (uint8_t)(pos[c] < n_short ? L - 1 : L);
+#pragma unroll
+        for (int i = 1; i <= 15; i++)
+            count[i] = (uint32_t)i == L - 1 ? n_short : ((uint32_t)i == L ? m - n_short : 0u);
+    }
+    else if (m == 1) {
+        if (lane == 0)
+            w.len[w.keys[0] & 0x1ffu] = 1;
+        count[1] = 1;
+    }
+    else {
+        // ---- bitonic sort of keys[0..P), P = power of two >= m, padded with the maximum ----
+        uint32_t P = 2;
+        while (P < m)
+            P <<= 1;
+        for (uint32_t i = m + lane; i < P; i += 64)
+            w.keys[i] = 0xffffffffu;
+        wave_sync();
+        for (uint32_t k = 2; k <= P; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = lane; i < P; i += 64) {
+                    const uint32_t partner = i ^ j;
+                    if (partner > i) {
+                        const uint32_t a = w.keys[i], b = w.keys[partner];
+                        const bool ascending = (i & k) == 0;
+                        if ((a > b) == ascending) {
+                            w.keys[i] = b;
+                            w.keys[partner] = a;
+                        }
+                    }
+                }
+                wave_sync();
+            }
+        }
+        // ---- two-queue Huffman merge; both queues live in registers ----
+        uint32_t lw0 = lane < (int)m ? w.keys[lane] >> 9 : 0u;
+        uint32_t lw1 = lane + 64 < (int)m ? w.keys[lane + 64] >> 9 : 0u;
+        uint32_t lw2 = lane + 128 < (int)m ? w.keys[lane + 128] >> 9 : 0u;
+        uint32_t iw0 = 0, iw1 = 0, iw2 = 0;     // internal node k (k = 0 .. m-2), created in weight order
+        uint32_t leaf = 0, inode = 0;
+        for (uint32_t made = 0; made + 1 < m; made++) {
+            uint32_t sum = 0;
+#pragma unroll
+            for (int two = 0; two < 2; two++) {
+                const bool have_leaf = leaf < m, have_node = inode < made;
+                const uint32_t wl = have_leaf ? lane_array_get(lw0, lw1, lw2, leaf) : 0xffffffffu;
+                const uint32_t wn = have_node ? lane_array_get(iw0, iw1, iw2, inode) : 0xffffffffu;
+                if (have_leaf && (!have_node || wl <= wn)) {
+                    if (lane == 0)
+                        w.parent[leaf] = (uint16_t)(m + made);
+                    sum += wl;
+                    leaf++;
+                }
+                else {
+                    if (lane == 0)
+                        w.parent[m + inode] = (uint16_t)(m + made);
+                    sum += wn;
+                    inode++;
+                }
+            }
+            lane_array_set(iw0, iw1, iw2, made, sum, lane);
+        }
+        wave_sync();
+        // ---- leaf depths: every lane walks up from its leaves to the root ----
+        const uint32_t root = 2 * m - 2;
+        uint32_t depth[3];
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+            const uint32_t i = (uint32_t)(g * 64 + lane);
+            uint32_t d = 0;
+            if (i < m) {
+                uint32_t p = i;
+                while (p != root) {
+                    p = w.parent[p];
+                    d++;
+                }
+                if (d > 15)
+                    d = 15;
+            }
+            depth[g] = d;
+        }
+#pragma unroll
+        for (int L = 1; L <= 15; L++) {
+            uint32_t n = 0;
+#pragma unroll
+            for (int g = 0; g < 3; g++)
+                n += (uint32_t)__popcll(__ballot(depth[g] == (uint32_t)L && (uint32_t)(g * 64 + lane) < m));
+            count[L] = n;
+        }
+        // ---- cap at 15 bits: restore the Kraft equality (wave-uniform scalar loop) ----
+        {
+            uint32_t total = 0;
+#pragma unroll
+            for (int L = 1; L <= 15; L++)
+                total += count[L] << (15 - L);
+            while (total > (1u << 15)) {
+                count[15]--;
+#pragma unroll
+                for (int L = 14; L > 0; L--) {
+                    if (count[L]) {
+                        count[L]--;
+                        count[L + 1] += 2;
+                        break;
+                    }
+                }
+                total--;
+            }
+        }
+        // ---- lengths by rank: the most frequent symbol (last in the sorted list) gets the shortest ----
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+            const uint32_t i = (uint32_t)(g * 64 + lane);
+            if (i < m) {
+                const uint32_t from_top = m - 1 - i;
+                uint32_t cum = 0, L = 0;
+#pragma unroll
+                for (int k = 1; k <= 15; k++) {
+                    cum += count[k];
+                    if (L == 0 && from_top < cum)
+                        L = (uint32_t)k;
+                }
+                w.len[w.keys[i] & 0x1ffu] = (uint8_t)L;
+            }
+        }
+    }
+    // distance alphabet: codes 0 (distance 1) and 15 (distance 256)
+    if (lane < 32)
+        w.len[288 + lane] = 0;
+    wave_sync();
+    const uint32_t dl0 = n_near ? 1u : 0u, dl15 = n_far ? 1u : 0u;
+    if (lane == 0) {
+        w.len[288] = (uint8_t)dl0;
+        w.len[288 + 15] = (uint8_t)dl15;
+        book->dist_len[0] = (uint8_t)dl0;
+        book->dist_len[1] = (uint8_t)dl15;
+        book->dist_code[0] = 0;
+        book->dist_code[1] = (uint16_t)((n_near && n_far) ? 1 : 0);
+    }
+    wave_sync();
+
+    // ---- canonical codes (RFC 1951 3.2.2) and the stream's body size ----
+    uint32_t next_code[16];
+    {
+        uint32_t c = 0;
+        next_code[0] = 0;
+#pragma unroll
+        for (int L = 1; L <= 15; L++) {
+            c = (c + (L == 1 ? 0u : count[L - 1])) << 1;
+            next_code[L] = c;
+        }
+    }
+    uint32_t body_bits = 0;
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const int s = c * 64 + lane;
+        const uint32_t L = s < 288 ? w.len[s] : 0u;
+        uint32_t code = 0;
+#pragma unroll
+        for (int k = 1; k <= 15; k++) {
+            const unsigned long long mask = __ballot(L == (uint32_t)k);
+            if (L == (uint32_t)k)
+                code = bitrev(next_code[k] + (uint32_t)__popcll(mask & lt_mask), k);
+            next_code[k] += (uint32_t)__popcll(mask);
+        }
+        if (s < 288) {
+            book->lit_len[s] = (uint8_t)L;
+            book->lit_code[s] = (uint16_t)code;
+        }
+        if (s < kNumLit && h[c])
+            body_bits += h[c] * (L + (s > 256 ? (uint32_t)kLenExtra[s - 257] : 0u));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        body_bits += __shfl_xor(body_bits, off, 64);
+    body_bits += n_near * dl0 + n_far * (dl15 + 6u);
+
+    // ---- block header: fixed part by lane 0, the code lengths run-length coded in parallel ----
+    for (int i = lane; i < 64; i += 64)
+        w.hdr[i] = 0;
+    // hlit / hdist: trailing zero lengths are not sent
+    uint32_t hlit = 257;
+#pragma unroll
+    for (int c = 4; c < 5; c++) {
+        const int s = c * 64 + lane;            // symbols 256 .. 319
+        const unsigned long long mask = __ballot(s < kNumLit && w.len[s] != 0);
+        if (mask)
+            hlit = 256u + 64u - (uint32_t)__builtin_clzll(mask);     // highest live symbol + 1
+        if (hlit < 257u)
+            hlit = 257u;
+    }
+    hlit = uni(hlit);
+    const uint32_t hdist = n_far ? 16u : 1u;
+    const uint32_t total = hlit + hdist;
+    wave_sync();
+    if (lane == 0) {
+        BitWriter bw{ w.hdr, 16 };
+        w.hdr[0] = 0x78u | (0x9cu << 8);        // CMF: deflate, 32K window; FLG: check bits, level 2
+        bw.put(1, 1);                           // BFINAL
+        bw.put(2, 2);                           // BTYPE = 10, dynamic Huffman
+        bw.put(hlit - 257u, 5);
+        bw.put(hdist - 1u, 5);
+        bw.put(19 - 4, 4);                      // HCLEN: all 19
+        for (int i = 0; i < 19; i++)
+            bw.put(kClLen[kClOrder[i]], 3);
+    }
+    wave_sync();
+    const uint32_t fixed_bits = 16 + 3 + 5 + 5 + 4 + 19 * 3;
+    // the sequence of code lengths: lit/len 0..hlit-1, then distance codes 0..hdist-1
+    auto seq = [&](uint32_t i) -> int { return i < hlit ? w.len[i] : w.len[288 + (i - hlit)]; };
+    unsigned long long start_mask[5];
+    int v_at[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const uint32_t i = (uint32_t)(c * 64 + lane);
+        const bool in = i < total;
+        v_at[c] = in ? seq(i) : -1;
+        const bool start = in && (i == 0 || seq(i - 1) != v_at[c]);
+        start_mask[c] = __ballot(start);
+    }
+    uint32_t run_pos = fixed_bits;              // wave-uniform: bits before this chunk's runs
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const uint32_t i = (uint32_t)(c * 64 + lane);
+        const bool start = (start_mask[c] >> lane) & 1ull;
+        uint32_t run_len = 0;
+        if (start) {
+            // next run start after i, in this chunk or a later one
+            uint32_t nxt = total;
+            const unsigned long long rest = lane < 63 ? start_mask[c] >> (lane + 1) : 0ull;
+            if (rest) {
+                nxt = i + 1u + (uint32_t)__builtin_ctzll(rest);
+            }
+            else {
+#pragma unroll
+                for (int c2 = 4; c2 > 0; c2--)      // keep the nearest later chunk with a start
+                    if (c2 > c && start_mask[c2])
+                        nxt = (uint32_t)(c2 * 64) + (uint32_t)__builtin_ctzll(start_mask[c2]);
+            }
+            run_len = nxt - i;
+        }
+        const uint32_t bits = start ? rle_run(v_at[c], (int)run_len, nullptr, 0) : 0u;
+        uint32_t incl = bits;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, 64);
+            if (lane >= off)
+                incl += up;
+        }
+        if (start)
+            rle_run(v_at[c], (int)run_len, w.hdr, run_pos + incl - bits);
+        run_pos += uni(__shfl(incl, 63, 64));
+    }
+    wave_sync();
+    const uint32_t header_bits = run_pos;
+    book->header[lane] = w.hdr[lane];
+
+    if (lane == 0) {
+        const uint32_t bits_total = header_bits + body_bits;
+        uint32_t bytes = (bits_total + 7u) / 8u + 4u;
+        if (bytes > (uint32_t)kMaxStream - 64u)
+            bytes = (uint32_t)kMaxStream;       // stored fallback
+        const unsigned long long need = (bytes + (kSlotAlign - 1)) & ~(unsigned long long)(kSlotAlign - 1);
+        const unsigned long long slot = atomicAdd(job.cursor, need);
+        const bool fits = slot + need <= job.arena_cap;
+        book->header_bits = header_bits;
+        book->stream_bytes = bytes;
+        book->slot = fits ? (uint32_t)slot : 0xffffffffu;
+        job.table[(size_t)tile * 2] = fits ? (uint32_t)slot : 0xffffffffu;
+        job.table[(size_t)tile * 2 + 1] = fits ? bytes : 0u;
+    }
+}
+
+// ------------------------------------------------------------------------
 // pass C: measure, place and emit; one workgroup per tile
 // ------------------------------------------------------------------------
 template <bool SMALL>
@@ -897,8 +1313,13 @@ int gcn10_gpu_deflate_strip(gcn10_gpu_ctx *ctx, const uint8_t *const *rasters_de
     hipStream_t s = as_stream(ctx, stream);
     HIP_TRY(hipMemsetAsync(cursor_dev, 0, sizeof(unsigned long long), s));
     hipLaunchKernelGGL(deflate_stats_kernel, dim3((uint32_t)nblocks), dim3(kTile), sizeof(SharedA), s, job);
-    hipLaunchKernelGGL(deflate_codes_kernel, dim3(((uint32_t)nblocks + kBuildThreads - 1) / kBuildThreads),
-                       dim3(kBuildThreads), sizeof(Work) * kBuildThreads, s, job);
+    if (ctx->deflate_wave_codes)
+        hipLaunchKernelGGL(deflate_codes_wave_kernel,
+                           dim3(((uint32_t)nblocks + kWavesPerBlock - 1) / kWavesPerBlock),
+                           dim3(64 * kWavesPerBlock), 0, s, job);
+    else
+        hipLaunchKernelGGL(deflate_codes_kernel, dim3(((uint32_t)nblocks + kBuildThreads - 1) / kBuildThreads),
+                           dim3(kBuildThreads), sizeof(Work) * kBuildThreads, s, job);
     hipLaunchKernelGGL(deflate_emit_kernel<true>, dim3((uint32_t)nblocks), dim3(kTile), sizeof(SharedC<true>), s,
                        job);
     hipLaunchKernelGGL(deflate_emit_kernel<false>, dim3((uint32_t)nblocks), dim3(kTile), sizeof(SharedC<false>),

@@ -51,6 +51,7 @@ struct gcn10_gpu_ctx {
     int prefetch = -1;      // loads of the next trip issued before the current one is consumed:
                             // -1 = per kernel default (on for all-tables, off for single-table)
     hipEvent_t time_start = nullptr, time_stop = nullptr;  // one-shot: bracket the next strip kernel
+    int deflate_wave_codes = 1;     // pass B of the tile encoder: 1 = one wave per tile, 0 = one thread
     bool deflate_ready = false;     // LDS attributes of the tile encoder set on this device
     void *deflate_ws = nullptr;     // per-tile statistics + code books of the tile encoder
     size_t deflate_ws_cap = 0;

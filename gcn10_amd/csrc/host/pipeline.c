@@ -47,7 +47,10 @@ struct strip_buf {
     gcn10_event_t ev_h2d, ev_kernel, ev_d2h, ev_meta;
     /* GPU-side DEFLATE: compressed tiles of all 18 rasters of the strip */
     uint8_t *d_arena, *h_arena;             /* h_arena pinned */
-    size_t arena_cap;
+    size_t arena_cap;                       /* device arena: the encoder's worst case      */
+    size_t h_arena_cap;                     /* pinned arena: an eighth of it (>= 32 MB)    */
+    uint8_t *h_spill;                       /* pageable stand-in when a strip needs more   */
+    const uint8_t *h_tiles;                 /* where this strip's streams are: arena or spill */
     uint32_t *d_table, *h_table;            /* [18][tiles][2]; h_table pinned */
     unsigned long long *d_cursor, *h_cursor;
     const uint8_t **d_ptrs;                 /* device array of the 18 d_out pointers */
@@ -183,7 +186,7 @@ static void put_tiles_job(void *arg)
             const uint32_t size = tab[((size_t)ty * j->across + tx) * 2 + 1];
 
             if (off == 0xffffffffu || size == 0 || (size_t)off + size > j->b->arena_cap ||
-                gcn10_tiff_put_tile(j->tif, tx, j->ty0 + ty, j->b->h_arena + off, size) != 0) {
+                gcn10_tiff_put_tile(j->tif, tx, j->ty0 + ty, j->b->h_tiles + off, size) != 0) {
                 atomic_store(&j->w->failed, true);
                 goto done;
             }
@@ -246,9 +249,26 @@ static int drain_strip_inner(struct worker *w, struct strip_buf *b, gcn10_tiff_w
         }
         if (r->null_sink)
             return 0;
-        if (g->memcpy_d2h(w->ctx, b->h_arena, b->d_arena, used, w->s_d2h) != 0 ||
-            g->event_record(w->ctx, b->ev_d2h, w->s_d2h) != 0 || g->event_sync(w->ctx, b->ev_d2h) != 0)
-            goto gpu_error;
+        {
+            /* CN rasters compress to a few percent, so the pinned arena is an eighth of the
+             * worst case; a strip of noise that needs more takes a pageable detour */
+            uint8_t *dst = b->h_arena;
+
+            free(b->h_spill);
+            b->h_spill = NULL;
+            if (used > b->h_arena_cap) {
+                b->h_spill = malloc(used);
+                if (!b->h_spill) {
+                    wlog(w, "ERROR", true, "malloc failed for %zu bytes of compressed tiles", used);
+                    return -1;
+                }
+                dst = b->h_spill;
+            }
+            b->h_tiles = dst;
+            if (g->memcpy_d2h(w->ctx, dst, b->d_arena, used, w->s_d2h) != 0 ||
+                g->event_record(w->ctx, b->ev_d2h, w->s_d2h) != 0 || g->event_sync(w->ctx, b->ev_d2h) != 0)
+                goto gpu_error;
+        }
         for (int k = 0; k < GCN10_N_RASTERS; k++) {
             struct put_job *j = malloc(sizeof *j);
 
@@ -319,6 +339,8 @@ static void free_strip_buffers(struct worker *w)
             b->h_out[k] = b->d_out[k] = NULL;
         }
         if (b->h_arena) g->host_free(w->ctx, b->h_arena);
+        free(b->h_spill);
+        b->h_spill = NULL;
         if (b->d_arena) g->free(w->ctx, b->d_arena);
         if (b->h_table) g->host_free(w->ctx, b->h_table);
         if (b->d_table) g->free(w->ctx, b->d_table);
@@ -358,7 +380,14 @@ static int ensure_strip_buffers(struct worker *w, int W)
 
             b->arena_cap = g->deflate_arena_bound(W, w->run->strip_rows, GCN10_N_RASTERS);
             GPU_TRY(w, g->malloc(w->ctx, b->arena_cap, (void **)&b->d_arena));
-            GPU_TRY(w, g->host_alloc(w->ctx, b->arena_cap, (void **)&b->h_arena));
+            b->h_arena_cap = b->arena_cap / 8 > ((size_t)32 << 20) ? b->arena_cap / 8 : ((size_t)32 << 20);
+            if (getenv("GCN10_PINNED_ARENA_BYTES"))        /* tests: force the spill path */
+                b->h_arena_cap = (size_t)strtoull(getenv("GCN10_PINNED_ARENA_BYTES"), NULL, 10);
+            if (b->h_arena_cap < 4096)
+                b->h_arena_cap = 4096;
+            if (b->h_arena_cap > b->arena_cap)
+                b->h_arena_cap = b->arena_cap;
+            GPU_TRY(w, g->host_alloc(w->ctx, b->h_arena_cap, (void **)&b->h_arena));
             GPU_TRY(w, g->malloc(w->ctx, tiles * GCN10_N_RASTERS * 8, (void **)&b->d_table));
             GPU_TRY(w, g->host_alloc(w->ctx, tiles * GCN10_N_RASTERS * 8, (void **)&b->h_table));
             GPU_TRY(w, g->malloc(w->ctx, 8, (void **)&b->d_cursor));

@@ -260,3 +260,21 @@ def test_vrt_landcover_with_local_tile_mirror(tmp_path, tables):
     out = _run(tmp_path, "-c", "config.txt", "-o")
     assert out.returncode == 0
     assert "esa load failed for block 7" in (tmp_path / "logs" / "rank_0.log").read_text()
+
+
+@pytest.mark.gpu
+def test_compressed_tiles_spill_past_the_pinned_arena(tmp_path, tables):
+    """The pinned arena holds an eighth of the encoder's worst case; a strip that needs more goes
+    through a pageable buffer.  Forced here with a 64 KB arena: results must not change."""
+    esa, soil = _world(tmp_path, seed=41)
+    (tmp_path / "ids.txt").write_text("101\n")
+    out = _run(tmp_path, "-c", "config.txt", "-l", "ids.txt", env={"GCN10_PINNED_ARENA_BYTES": "65536"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    bid, *bbox = BLOCKS[0]
+    xo, yo, W, H, gt = oc.window(ESA_GT, 3000, 2000, bbox)
+    sxo, syo, hsx, hsy, sgt = oc.window(SOIL_GT, soil.shape[1], soil.shape[0], bbox)
+    want = oc.process_block_mem(esa[yo:yo + H, xo:xo + W], gt, soil[syo:syo + hsy, sxo:sxo + hsx], sgt, tables)
+    for r in range(18):
+        c, k = divmod(r, 9)
+        p = tmp_path / ("cn_rasters_%s" % CONDS[c]) / ("cn_%s_%s_%d.tif" % (HCS[k // 3], ARCS[k % 3], bid))
+        assert np.array_equal(np.array(Image.open(str(p))), want[r])

@@ -96,3 +96,20 @@ def test_argument_errors(engine):
     assert gpu.lib().gcn10_gpu_deflate_arena_bound(256, 256, 1) == 65552
     assert gpu.lib().gcn10_gpu_deflate_arena_bound(257, 256, 2) == 4 * 65552
     assert gpu.lib().gcn10_gpu_deflate_arena_bound(0, 256, 1) == 0
+
+
+@pytest.mark.parametrize("kind", ["patches", "noisy", "skewed", "manyvals", "rows", "uniform"])
+def test_wave_and_thread_code_construction_agree(engine, kind):
+    """Pass B exists in two forms (one wave per tile, one thread per tile) that implement the same
+    algorithm with the same tie breaks: every tile's stream must be byte-identical."""
+    H, W = 512, 768
+    img = _rasters(kind, H, W, 7)
+    buf = engine.upload(img)
+    streams = {}
+    for mode in (1, 0):
+        engine.set_option("deflate_wave_codes", mode)
+        data, table, used = engine.deflate_rasters([buf.ptr], W, H)
+        streams[mode] = [data[int(o):int(o) + int(n)].tobytes() for o, n in table.reshape(-1, 2)]
+    engine.set_option("deflate_wave_codes", 1)
+    buf.close()
+    assert streams[0] == streams[1]
