@@ -836,6 +836,14 @@ int gcn10_gpu_device_info(gcn10_gpu_ctx *ctx, char *name, size_t cap, size_t *hb
     return prop.multiProcessorCount;
 }
 
+int gcn10_gpu_pci_bus_id(int device, char *buf, size_t cap)
+{
+    if (!buf || cap < 13)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_pci_bus_id: buffer too small");
+    HIP_TRY(hipDeviceGetPCIBusId(buf, (int)cap, device));
+    return GCN10_OK;
+}
+
 // ---- memory / streams / events ------------------------------------------
 
 int gcn10_gpu_malloc(gcn10_gpu_ctx *ctx, size_t bytes, void **dptr)

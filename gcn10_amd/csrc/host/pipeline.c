@@ -24,6 +24,7 @@
 #include <errno.h>
 #include <limits.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdarg.h>
 #include <stdatomic.h>
 #include <stdio.h>
@@ -706,6 +707,62 @@ static void worker_teardown(struct worker *w)
     }
 }
 
+/* Keeps a worker thread (and the pinned buffers it is about to allocate: first touch)
+ * on the NUMA node its GPU hangs off.  Best effort: any failure leaves the thread alone. */
+static void bind_to_gpu_numa_node(struct worker *w, int device)
+{
+    char bus[64] = "", path[256], line[4096];
+    FILE *f;
+    int node = -1;
+    cpu_set_t set;
+    char *p;
+
+    if (getenv("GCN10_NO_NUMA_BIND") || w->run->gpu->pci_bus_id(device, bus, sizeof bus) != 0)
+        return;
+    for (char *c = bus; *c; c++)
+        if (*c >= 'A' && *c <= 'F')
+            *c = (char)(*c - 'A' + 'a');        /* sysfs names are lower case */
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    f = fopen(path, "r");
+    if (!f)
+        return;
+    if (fscanf(f, "%d", &node) != 1)
+        node = -1;
+    fclose(f);
+    if (node < 0)
+        return;
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f)
+        return;
+    if (!fgets(line, sizeof line, f)) {
+        fclose(f);
+        return;
+    }
+    fclose(f);
+    CPU_ZERO(&set);
+    for (p = line; *p;) {                       /* "0-31,64-95" */
+        char *end;
+        long a = strtol(p, &end, 10), b;
+
+        if (end == p)
+            break;
+        b = a;
+        if (*end == '-') {
+            p = end + 1;
+            b = strtol(p, &end, 10);
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            CPU_SET((int)c, &set);
+        p = (*end == ',') ? end + 1 : end;
+        if (*end != ',')
+            break;
+    }
+    if (CPU_COUNT(&set) > 0 && sched_setaffinity(0, sizeof set, &set) == 0)
+        wlog(w, "INFO", false, "gpu %d (%s) is on NUMA node %d: worker bound to its %d cpus", device, bus,
+             node, CPU_COUNT(&set));
+}
+
 static int worker_setup(struct worker *w)
 {
     struct run *r = w->run;
@@ -717,6 +774,7 @@ static int worker_setup(struct worker *w)
         pthread_cond_init(&w->buf[i].cv, NULL);
         w->buf[i].owner = w;
     }
+    bind_to_gpu_numa_node(w, w->index % r->n_devices);
     if (g->init(w->index % r->n_devices, &w->ctx) != 0) {
         wlog(w, "ERROR", true, "gpu %d: %s", w->index % r->n_devices, g->last_error());
         return -1;

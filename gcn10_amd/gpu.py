@@ -39,6 +39,7 @@ ABI_SYMBOLS = (
     "gcn10_gpu_calculate_cn", "gcn10_gpu_prepare_tile", "gcn10_gpu_cn_strip",
     "gcn10_gpu_strip_algorithmic_bytes", "gcn10_gpu_last_kernel_name", "gcn10_gpu_set_option",
     "gcn10_gpu_deflate_arena_bound", "gcn10_gpu_deflate_strip", "gcn10_gpu_time_next_strip",
+    "gcn10_gpu_pci_bus_id",
 )
 
 
@@ -91,6 +92,7 @@ def lib():
             "gcn10_gpu_last_kernel_name": (C.c_char_p, [vp]),
             "gcn10_gpu_set_option": (i, [vp, C.c_char_p, i]),
             "gcn10_gpu_time_next_strip": (i, [vp, vp, vp]),
+            "gcn10_gpu_pci_bus_id": (i, [i, C.c_char_p, sz]),
             "gcn10_gpu_deflate_arena_bound": (sz, [i, i, i]),
             "gcn10_gpu_deflate_strip": (i, [vp, vp, i, i, i, vp, sz, vp, vp, vp]),
         }

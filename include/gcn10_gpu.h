@@ -69,6 +69,10 @@ const char *gcn10_gpu_last_error(void);
 int gcn10_gpu_device_info(gcn10_gpu_ctx *ctx, char *name, size_t cap,
                           size_t *hbm_bytes);
 
+/* PCI address of HIP device `device` as "dddd:bb:dd.f" (for NUMA placement of the
+ * host thread that feeds it); works without a context.  0 or <0. */
+int gcn10_gpu_pci_bus_id(int device, char *buf, size_t cap);
+
 /* ---- memory, streams, events ------------------------------------------ */
 /* The reference mallocs every raster on the host (src/raster.c:169,
  * src/cn.c:209,264,278).  Here rasters live in HBM; the host stages them
