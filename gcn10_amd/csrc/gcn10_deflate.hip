@@ -387,7 +387,11 @@ __global__ __launch_bounds__(kTile) void deflate_stats_kernel(const TileJob job)
     RowMasks m;
     row_masks(sh.tile, t, m);
     parse_row<kCount>(sh.tile, t, m, sh.lit_hist, sh.dist_hist, nullptr, nullptr);
-    __syncthreads();
+    // a tile of one value (ocean, no-data: most of the globe): every byte repeats its
+    // predecessor.  Pass C then emits it without loading the tile again.
+    const bool row_constant = (m.near_[0] | (t == 0 ? 1ull : 0ull)) == ~0ull && m.near_[1] == ~0ull &&
+                              m.near_[2] == ~0ull && m.near_[3] == ~0ull;
+    const bool tile_uniform = __syncthreads_and(row_constant) != 0;
 
     uint32_t *out = job.hist + (size_t)blockIdx.x * kHistWords;
     for (int i = t; i < 288; i += kTile)
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(kTile) void deflate_stats_kernel(const TileJob job)
         const uint32_t s1 = (1u + sh.adler_a[0]) % 65521u;
         const uint32_t s2 = (uint32_t)(((unsigned long long)kTileBytes + sh.adler_b[0]) % 65521ull);
         out[290] = (s2 << 16) | s1;
-        out[291] = 0;
+        out[291] = tile_uniform ? (1u | ((uint32_t)sh.tile[0] << 8)) : 0u;
     }
 }
 
@@ -1168,8 +1172,11 @@ __global__ __launch_bounds__(kTile) void deflate_emit_kernel(const TileJob job)
     const uint32_t adler = job.hist[(size_t)blockIdx.x * kHistWords + 290];
     const bool stored = stream_bytes == (uint32_t)kMaxStream;
     const uint32_t n_words = (stream_bytes + 3) / 4;
+    const uint32_t uniform_word = job.hist[(size_t)blockIdx.x * kHistWords + 291];
+    const bool uniform = (uniform_word & 1u) != 0 && !stored;     // one-value tile: no need for its bytes
 
-    load_tile(job, job.rasters[raster], tx, ty, sh.tile, t);
+    if (!uniform)
+        load_tile(job, job.rasters[raster], tx, ty, sh.tile, t);
     // the output image: block header from pass B, zeros up to the stream's end
     for (uint32_t i = t; i < n_words + 1; i += kTile)
         sh.out[i] = (i < 64 && !stored) ? book->header[i] : 0u;
@@ -1187,7 +1194,24 @@ __global__ __launch_bounds__(kTile) void deflate_emit_kernel(const TileJob job)
     __syncthreads();
 
     uint8_t *o = reinterpret_cast<uint8_t *>(sh.out);
-    if (!stored) {
+    if (uniform) {
+        // the greedy parse of a one-value tile, written out: row 0 = literal + match(255, 1),
+        // every other row = match(256, 1); both lengths use length code 27 (227..257, 5 extra bits)
+        const uint32_t v = (uniform_word >> 8) & 0xffu;
+        const int ls = 257 + 27;
+        const uint32_t match_bits = (uint32_t)sh.lit_len[ls] + 5u + cv.dist_len[0];
+        const uint32_t row0_bits = (uint32_t)sh.lit_len[v] + match_bits;
+        RowEmitter em{ sh.out, header_bits + (t == 0 ? 0u : row0_bits + (uint32_t)(t - 1) * match_bits), 0ull, 0 };
+        if (t == 0)
+            em.put(sh.lit_code[v], sh.lit_len[v]);
+        em.put(sh.lit_code[ls], sh.lit_len[ls]);
+        em.put((uint32_t)((t == 0 ? 255 : 256) - 227), 5);
+        em.put(cv.dist_code[0], cv.dist_len[0]);
+        if (t == kTile - 1)
+            em.put(sh.lit_code[256], sh.lit_len[256]);      // end of block
+        em.finish();
+    }
+    else if (!stored) {
         RowMasks m;
         row_masks(sh.tile, t, m);
         const uint32_t bits = parse_row<kMeasure>(sh.tile, t, m, nullptr, nullptr, &cv, nullptr);
