@@ -44,7 +44,7 @@ struct gcn10_gpu_ctx {
     char kernel_name[96] = "";
     // tuning knobs (gcn10_gpu_set_option); defaults = the round-1 measured best
     int grid_blocks_per_cu = 16;
-    int ilp16 = 1;          // sub-chunks per loop trip, all-tables kernel (1, 2)
+    int ilp16 = 0;          // sub-chunks per loop trip, all-tables kernel (1, 2; 0 = by stream count)
     int ilp1 = 2;           // same, single-table kernel (1, 2, 4)
     int nontemporal = 1;
     int xcd_slabs = 1;

@@ -188,7 +188,7 @@ int gcn10_gpu_deflate_strip(gcn10_gpu_ctx *ctx, const uint8_t *const *rasters_de
                             unsigned long long *cursor_dev, gcn10_stream_t stream);
 
 /* Launch-shape knobs of the strip kernels, for tuning runs; results never
- * depend on them.  Names: "grid_blocks_per_cu" (1..64), "ilp16" (1|2),
+ * depend on them.  Names: "grid_blocks_per_cu" (1..64), "ilp16" (0 = by raster count | 1 | 2),
  * "ilp1" (1|2|4), "nontemporal" (0|1), "xcd_slabs" (0|1), "prefetch" (-1 = per-kernel default | 0 | 1), "deflate_wave_codes" (0|1: code
  * construction of the tile encoder by one thread or one wave per tile). */
 int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value);
