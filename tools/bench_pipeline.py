@@ -34,8 +34,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--modes", default="null,files")
     ap.add_argument("--pattern", default="patches")
+    ap.add_argument("--reuse", action="store_true", help="reuse the world already in --workdir")
+    ap.add_argument("--keep", action="store_true", help="do not delete --workdir at the end")
     ap.add_argument("--deflate-level", type=int, default=0)
     ap.add_argument("--gpu-deflate", type=int, default=1)
+    ap.add_argument("--workers-per-gpu", type=int, default=0)
     ap.add_argument("--real-vrt-pixel", action="store_true",
                     help="use the shipped VRT's pixel size 8.3333333333330430e-05: 3-degree blocks become "
                          "36001 px wide (SURVEY.md section 7), rows are not 16-byte aligned")
@@ -43,13 +46,28 @@ def main():
                     help="TIFF compression of the landcover input: 1 none, 8 DEFLATE (like the ESA COGs), 5 LZW")
     a = ap.parse_args()
     wd = a.workdir
-    shutil.rmtree(wd, ignore_errors=True)
-    os.makedirs(wd)
     size, nb = a.size, a.blocks
+    reuse = a.reuse and os.path.exists(os.path.join(wd, "esa.tif"))
+    if not reuse:
+        shutil.rmtree(wd, ignore_errors=True)
+        os.makedirs(wd)
     px = 3.0 / size
     if a.real_vrt_pixel:
         size, px = 36001, 8.3333333333330430e-05
     t0 = time.time()
+    if not reuse:
+        build_world(a, wd, size, nb, px)
+    with open(os.path.join(wd, "config.txt"), "w") as f:
+        f.write("hysogs_data_path=%s/soil.tif\nesa_data_path=%s/esa.tif\nblocks_shp_path=%s/blocks.shp\n"
+                "lookup_table_path=%s\nlog_dir=%s/logs\nstrip_rows=%d\ndeflate_level=%d\ngpu_deflate=%d\n"
+                "workers_per_gpu=%d\n"
+                % (wd, wd, wd, os.path.join(ROOT, "tests", "golden", "lookups"), wd, a.strip_rows,
+                   a.deflate_level, a.gpu_deflate, a.workers_per_gpu))
+    build_s = time.time() - t0
+    run_modes(a, wd, size, nb, build_s)
+
+
+def build_world(a, wd, size, nb, px):
     # landcover: nb blocks side by side (lon 0..3*nb, lat 0..3), written tile-wise without
     # holding more than one block in memory
     esa1, _, coarse1, _ = bench.synth_block(1, size, a.pattern)
@@ -64,13 +82,10 @@ def main():
                         compression=8, rows_per_strip=64)
     tiffutil.write_block_shapefile(os.path.join(wd, "blocks"),
                                    [(i + 1, 3.0 * i, 0.0, 3.0 * (i + 1), 3.0) for i in range(nb)])
-    with open(os.path.join(wd, "config.txt"), "w") as f:
-        f.write("hysogs_data_path=%s/soil.tif\nesa_data_path=%s/esa.tif\nblocks_shp_path=%s/blocks.shp\n"
-                "lookup_table_path=%s\nlog_dir=%s/logs\nstrip_rows=%d\ndeflate_level=%d\ngpu_deflate=%d\n"
-                % (wd, wd, wd, os.path.join(ROOT, "tests", "golden", "lookups"), wd, a.strip_rows,
-                   a.deflate_level, a.gpu_deflate))
-    build_s = time.time() - t0
-    res = {"size": size, "blocks": nb, "strip_rows": a.strip_rows, "gpus": a.gpus, "pattern": a.pattern, "gpu_deflate": a.gpu_deflate, "esa_compression": a.esa_compression,
+
+
+def run_modes(a, wd, size, nb, build_s):
+    res = {"size": size, "blocks": nb, "strip_rows": a.strip_rows, "gpus": a.gpus, "pattern": a.pattern, "gpu_deflate": a.gpu_deflate, "workers_per_gpu": a.workers_per_gpu, "esa_compression": a.esa_compression,
            "world_build_seconds": round(build_s, 1), "modes": {}}
     for mode in a.modes.split(","):
         env = dict(os.environ)
@@ -96,7 +111,10 @@ def main():
                               "seconds_per_block": round(secs / done, 3) if done else None,
                               "output_bytes": nbytes, "stderr_tail": out.stderr[-300:] if out.returncode else ""}
     print(json.dumps(res))
-    shutil.rmtree(wd, ignore_errors=True)
+    for d in ("cn_rasters_drained", "cn_rasters_undrained", "logs"):
+        shutil.rmtree(os.path.join(wd, d), ignore_errors=True)
+    if not a.keep:
+        shutil.rmtree(wd, ignore_errors=True)
 
 
 if __name__ == "__main__":
