@@ -1260,6 +1260,297 @@ __global__ __launch_bounds__(kTile) void deflate_emit_kernel(const TileJob job)
     }
 }
 
+// ------------------------------------------------------------------------
+// Fused tile encoder: the 18 rasters of a block are functions of the same (landcover,
+// soil) pixel pairs, so their repeats line up.  Pixels are reduced to a CLASS id (two
+// pixels share a class iff all 18 rasters agree on them; gcn10_gpu_set_tables builds
+// the map), the class tile is loaded, masked and tokenised ONCE per tile position, and
+// the 18 streams are produced from it: no CN raster is ever written to or read from HBM
+// (24.6 GB written + 2 x 23.3 GB read per block in the unfused path -> 1.4 GB read).
+// A match of the class stream is a match in every raster; a raster's own extra repeats
+// (two classes with the same value in that raster) are coded as literals, which costs a
+// little compression.  Passes: F-A statistics per tile position -> B code construction
+// per (raster, tile), unchanged -> F-C emission per tile position, looping over rasters.
+// ------------------------------------------------------------------------
+struct FusedJob {
+    const uint8_t *esa;
+    const uint8_t *hx;
+    const int32_t *cj;
+    const uint8_t *class_of;        // [36][256]; class_val [18][256] follows
+    uint32_t hx_stride, hx_rows;
+    uint32_t n_sel;                 // selected rasters, ascending
+    uint8_t sel[GCN10_N_RASTERS];
+    TileJob t;
+};
+
+__device__ __forceinline__ uint32_t compact_code(uint32_t code)
+{
+    return (code & 15u) * 6u + (code >> 4);
+}
+
+// Class ids of one tile position into LDS (row stride kRowStride); class 0 outside the raster.
+__device__ __forceinline__ void load_class_tile(const FusedJob &job, uint32_t tx, uint32_t ty,
+                                                const uint8_t *class_of_lds, uint8_t *tile, int t)
+{
+    typedef uint32_t u32_u __attribute__((aligned(1)));
+    const uint32_t W = job.t.W, rows = job.t.rows;
+    const uint32_t x = tx * kTile + (uint32_t)(t & 63) * 4u;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(tile) + (t & 63);
+#pragma unroll 4
+    for (int i = 0; i < kTile / 4; i++) {
+        const int r = i * 4 + (t >> 6);
+        const uint32_t y = ty * kTile + (uint32_t)r;
+        uint32_t out = 0;
+        if (y < rows && x < W) {
+            uint32_t srow = (uint32_t)job.cj[y];
+            srow = srow < job.hx_rows ? srow : job.hx_rows - 1u;
+            const uint8_t *pe = job.esa + (size_t)y * W + x;
+            // hx rows are padded by >= 16 bytes past W: a 4-byte read starting below W is safe
+            const uint32_t c4 = *reinterpret_cast<const u32_u *>(job.hx + (size_t)srow * job.hx_stride + x);
+            uint32_t e4 = 0;
+            if (x + 4u <= W) {
+                e4 = *reinterpret_cast<const u32_u *>(pe);
+            }
+            else {
+                for (uint32_t k = 0; x + k < W; k++)
+                    e4 |= (uint32_t)pe[k] << (8 * k);
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {
+                if (x + q < W) {
+                    const uint32_t lc = (e4 >> (8 * q)) & 0xffu;
+                    const uint32_t cc = compact_code((c4 >> (8 * q)) & 0xffu);
+                    out |= (uint32_t)class_of_lds[cc * 256u + lc] << (8 * q);
+                }
+            }
+        }
+        dst[r * (kRowStride / 4)] = out;
+    }
+}
+
+struct SharedFA {
+    uint8_t tile[kTile * kRowStride];
+    uint8_t class_of[gcn10::kClassCodes * 256];
+    uint8_t class_val[GCN10_N_RASTERS * 256];
+    uint32_t lit_hist[288];         // literals by class, match length symbols at 257..
+    uint32_t dist_hist[2];
+    uint32_t n_c[256], w_c[256];    // pixels per class, sum of their Adler position weights
+    uint32_t H[GCN10_N_RASTERS][288];
+    uint32_t adler[GCN10_N_RASTERS];
+};
+
+__global__ __launch_bounds__(kTile) void fused_stats_kernel(const FusedJob job)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    SharedFA &sh = *reinterpret_cast<SharedFA *>(smem);
+    const int t = threadIdx.x;
+    const uint32_t tiles = job.t.across * job.t.down;
+    const uint32_t tix = blockIdx.x;
+    const uint32_t ty = tix / job.t.across, tx = tix - ty * job.t.across;
+
+    for (int i = t; i < (gcn10::kClassCodes * 256 + GCN10_N_RASTERS * 256) / 4; i += kTile)
+        reinterpret_cast<uint32_t *>(sh.class_of)[i] = reinterpret_cast<const uint32_t *>(job.class_of)[i];
+    for (int i = t; i < 288; i += kTile)
+        sh.lit_hist[i] = 0;
+    if (t < 2)
+        sh.dist_hist[t] = 0;
+    sh.n_c[t] = 0;
+    sh.w_c[t] = 0;
+    for (int i = t; i < GCN10_N_RASTERS * 288; i += kTile)
+        (&sh.H[0][0])[i] = 0;
+    __syncthreads();
+    load_class_tile(job, tx, ty, sh.class_of, sh.tile, t);
+    __syncthreads();
+
+    // pixels and Adler weights per class, run by run along row t (weight of byte i: 65536 - i)
+    {
+        const uint8_t *row = sh.tile + t * kRowStride;
+        uint32_t cur = row[0], n = 1;
+        uint32_t wgt = (uint32_t)kTileBytes - (uint32_t)t * kTile;
+        uint32_t wsum = wgt;
+        for (int x = 1; x < kTile; x++) {
+            const uint32_t c = row[x];
+            wgt--;
+            if (c == cur) {
+                n++;
+                wsum += wgt;
+            }
+            else {
+                atomicAdd(&sh.n_c[cur], n);
+                atomicAdd(&sh.w_c[cur], wsum);
+                cur = c;
+                n = 1;
+                wsum = wgt;
+            }
+        }
+        atomicAdd(&sh.n_c[cur], n);
+        atomicAdd(&sh.w_c[cur], wsum);
+    }
+    RowMasks m;
+    row_masks(sh.tile, t, m);
+    parse_row<kCount>(sh.tile, t, m, sh.lit_hist, sh.dist_hist, nullptr, nullptr);
+    __syncthreads();
+
+    // per raster: literal counts by VALUE, and the Adler-32 of the raster's tile
+    {
+        const uint32_t lits = sh.lit_hist[t];       // thread t = class t
+        if (lits)
+            for (uint32_t j = 0; j < job.n_sel; j++)
+                atomicAdd(&sh.H[j][sh.class_val[job.sel[j] * 256 + t]], lits);
+        if ((uint32_t)t < job.n_sel) {
+            const uint8_t *val = sh.class_val + job.sel[t] * 256;
+            unsigned long long s1 = 1, s2 = (unsigned long long)kTileBytes;
+            for (int c = 0; c < 256; c++) {
+                s1 += (unsigned long long)sh.n_c[c] * val[c];
+                s2 += (unsigned long long)sh.w_c[c] * val[c];
+            }
+            sh.adler[t] = (uint32_t)(((s2 % 65521ull) << 16) | (s1 % 65521ull));
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = 0; j < job.n_sel; j++) {
+        uint32_t *out = job.t.hist + ((size_t)j * tiles + tix) * kHistWords;
+        for (int i = t; i < kHistWords; i += kTile) {
+            uint32_t v;
+            if (i < 256)
+                v = sh.H[j][i];
+            else if (i == 256)
+                v = 1u;                             // end of block
+            else if (i < 288)
+                v = sh.lit_hist[i];                 // match length symbols: the same for every raster
+            else if (i < 290)
+                v = sh.dist_hist[i - 288];
+            else if (i == 290)
+                v = sh.adler[j];
+            else
+                v = 0u;
+            out[i] = v;
+        }
+    }
+}
+
+template <bool SMALL>
+struct SharedFC {
+    static constexpr int kWords = SMALL ? 12288 / 4 + 16 : kOutWords;
+    uint8_t tile[kTile * kRowStride];
+    uint32_t out[kWords];           // doubles as the staging area of class_of while the tile is built
+    uint8_t lit_len[288];           // per CLASS for indices < 256, then end of block and match symbols
+    uint16_t lit_code[288];
+    uint32_t wave_sum[4];
+};
+constexpr int kFusedSmallStream = 12288;
+
+template <bool SMALL>
+__global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    SharedFC<SMALL> &sh = *reinterpret_cast<SharedFC<SMALL> *>(smem);
+    const int t = threadIdx.x;
+    const uint32_t tiles = job.t.across * job.t.down;
+    const uint32_t tix = blockIdx.x;
+    const uint32_t ty = tix / job.t.across, tx = tix - ty * job.t.across;
+
+    // anything to do for this tile position in this launch?
+    {
+        int mine = 0;
+        if ((uint32_t)t < job.n_sel) {
+            const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)t * tiles + tix) * kBookBytes);
+            mine = ((b->stream_bytes <= (uint32_t)kFusedSmallStream) == SMALL) && b->slot != 0xffffffffu;
+        }
+        if (!__syncthreads_or(mine))
+            return;
+    }
+    static_assert(SharedFC<SMALL>::kWords * 4 >= gcn10::kClassCodes * 256, "class map must fit the output image");
+    uint8_t *class_of_lds = reinterpret_cast<uint8_t *>(sh.out);
+    for (int i = t; i < gcn10::kClassCodes * 256 / 4; i += kTile)
+        reinterpret_cast<uint32_t *>(class_of_lds)[i] = reinterpret_cast<const uint32_t *>(job.class_of)[i];
+    __syncthreads();
+    load_class_tile(job, tx, ty, class_of_lds, sh.tile, t);
+    __syncthreads();
+    RowMasks m;
+    row_masks(sh.tile, t, m);
+    const uint8_t *class_val = job.class_of + gcn10::kClassCodes * 256;
+    uint8_t *o = reinterpret_cast<uint8_t *>(sh.out);
+
+    for (uint32_t j = 0; j < job.n_sel; j++) {
+        const Book *book = reinterpret_cast<const Book *>(job.t.books + ((size_t)j * tiles + tix) * kBookBytes);
+        const uint32_t stream_bytes = book->stream_bytes;
+        const uint32_t slot = book->slot;
+        if (((stream_bytes <= (uint32_t)kFusedSmallStream) != SMALL) || slot == 0xffffffffu)
+            continue;                               // block-uniform
+        const bool stored = stream_bytes == (uint32_t)kMaxStream;
+        const uint32_t n_words = (stream_bytes + 3) / 4;
+        const uint32_t header_bits = book->header_bits;
+        const uint32_t adler = job.t.hist[((size_t)j * tiles + tix) * kHistWords + 290];
+        const uint8_t my_val = class_val[job.sel[j] * 256 + t];     // value of class t in this raster
+
+        __syncthreads();                            // the previous raster's image has been copied out
+        for (uint32_t i = t; i < n_words + 1; i += kTile)
+            sh.out[i] = (i < 64 && !stored) ? book->header[i] : 0u;
+        // code tables by class: a literal of class c is the symbol val(c)
+        sh.lit_len[t] = book->lit_len[my_val];
+        sh.lit_code[t] = book->lit_code[my_val];
+        if (t < 32) {
+            sh.lit_len[256 + t] = book->lit_len[256 + t];
+            sh.lit_code[256 + t] = book->lit_code[256 + t];
+        }
+        CodeView cv;
+        cv.lit_len = sh.lit_len;
+        cv.lit_code = sh.lit_code;
+        cv.dist_len[0] = book->dist_len[0];
+        cv.dist_len[1] = book->dist_len[1];
+        cv.dist_code[0] = book->dist_code[0];
+        cv.dist_code[1] = book->dist_code[1];
+        __syncthreads();
+
+        if (!stored) {
+            const uint32_t bits = parse_row<kMeasure>(sh.tile, t, m, nullptr, nullptr, &cv, nullptr);
+            const uint32_t incl = block_scan(bits, sh.wave_sum, t);
+            RowEmitter em{ sh.out, header_bits + incl - bits, 0ull, 0 };
+            parse_row<kEmit>(sh.tile, t, m, nullptr, nullptr, &cv, &em);
+            if (t == kTile - 1)
+                em.put(sh.lit_code[256], sh.lit_len[256]);      // end of block
+            em.finish();
+        }
+        else if (!SMALL) {
+            // stored fallback: the raster's bytes are val(class), two blocks of 32768 bytes
+            if (t == 0) {
+                o[0] = 0x78;
+                o[1] = 0x01;
+                for (int b = 0; b < 2; b++) {
+                    uint8_t *h = o + 2 + b * (5 + 32768);
+                    h[0] = (uint8_t)(b == 1);
+                    h[1] = 0x00;
+                    h[2] = 0x80;
+                    h[3] = 0xff;
+                    h[4] = 0x7f;
+                }
+            }
+            uint8_t *dst = o + 2 + (t >> 7) * (5 + 32768) + 5 + (t & 127) * kTile;
+            const uint8_t *row = sh.tile + t * kRowStride;
+            const uint8_t *val = class_val + job.sel[j] * 256;
+            for (int k = 0; k < kTile; k++)
+                dst[k] = val[row[k]];
+        }
+        __syncthreads();
+        if (t == 0) {
+            const uint32_t at = stream_bytes - 4;
+            o[at] = (uint8_t)(adler >> 24);
+            o[at + 1] = (uint8_t)(adler >> 16);
+            o[at + 2] = (uint8_t)(adler >> 8);
+            o[at + 3] = (uint8_t)adler;
+        }
+        __syncthreads();
+        {
+            const uint32_t nvec = (stream_bytes + 15) / 16;
+            u32x4 *dst = reinterpret_cast<u32x4 *>(job.t.arena + slot);
+            const u32x4 *srcv = reinterpret_cast<const u32x4 *>(sh.out);
+            for (uint32_t i = t; i < nvec; i += kTile)
+                dst[i] = srcv[i];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1348,6 +1639,102 @@ int gcn10_gpu_deflate_strip(gcn10_gpu_ctx *ctx, const uint8_t *const *rasters_de
                        job);
     hipLaunchKernelGGL(deflate_emit_kernel<false>, dim3((uint32_t)nblocks), dim3(kTile), sizeof(SharedC<false>),
                        s, job);
+    HIP_TRY(hipGetLastError());
+    return GCN10_OK;
+}
+
+int gcn10_gpu_deflate_fused_available(gcn10_gpu_ctx *ctx)
+{
+    return ctx && ctx->n_tables > 0 && ctx->n_classes > 0 ? 1 : 0;
+}
+
+int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, int rows, const int32_t *cj,
+                                  unsigned cond_mask, unsigned table_mask, uint8_t *arena_dev, size_t arena_cap,
+                                  uint32_t *table_dev, unsigned long long *cursor_dev, gcn10_stream_t stream)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (ctx->n_tables == 0)
+        return fail(GCN10_E_STATE, "gcn10_gpu_deflate_fused_strip: call gcn10_gpu_set_tables first");
+    if (ctx->n_classes == 0)
+        return fail(GCN10_E_STATE, "gcn10_gpu_deflate_fused_strip: the lookup tables define more than 256 pixel "
+                                   "classes; use gcn10_gpu_cn_strip + gcn10_gpu_deflate_strip");
+    if (!ctx->d_hx || ctx->hx_W == 0 || (uint32_t)W != ctx->hx_W)
+        return fail(GCN10_E_STATE, "gcn10_gpu_deflate_fused_strip: call gcn10_gpu_prepare_tile for W=%d first", W);
+    if (W <= 0 || rows < 0 || cond_mask == 0 || (cond_mask & ~3u) || table_mask == 0 ||
+        (table_mask >> ctx->n_tables))
+        return fail(GCN10_E_INVAL, "gcn10_gpu_deflate_fused_strip: bad shape or masks");
+    if (rows == 0)
+        return GCN10_OK;
+    if (!esa || !cj || !arena_dev || !table_dev || !cursor_dev)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_deflate_fused_strip: null pointer");
+    if ((reinterpret_cast<uintptr_t>(arena_dev) & 15u) != 0)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_deflate_fused_strip: arena must be 16-byte aligned");
+
+    FusedJob job;
+    memset(&job, 0, sizeof job);
+    job.esa = esa;
+    job.hx = ctx->d_hx;
+    job.cj = cj;
+    job.class_of = ctx->d_class_of;
+    job.hx_stride = ctx->hx_stride;
+    job.hx_rows = ctx->hx_rows;
+    for (int r = 0; r < GCN10_N_RASTERS; r++)
+        if ((cond_mask >> (r / 9)) & 1u && (table_mask >> (r % 9)) & 1u)
+            job.sel[job.n_sel++] = (uint8_t)r;
+    job.t.arena = arena_dev;
+    job.t.table = table_dev;
+    job.t.cursor = cursor_dev;
+    job.t.W = (uint32_t)W;
+    job.t.rows = (uint32_t)rows;
+    job.t.across = ((uint32_t)W + kTile - 1) / kTile;
+    job.t.down = ((uint32_t)rows + kTile - 1) / kTile;
+    job.t.arena_cap = arena_cap;
+    const uint32_t positions = job.t.across * job.t.down;
+    const uint64_t nblocks = (uint64_t)positions * job.n_sel;
+    job.t.n_tiles = (uint32_t)nblocks;
+
+    const size_t need = (size_t)nblocks * ((size_t)kHistWords * 4 + (size_t)kBookBytes);
+    if (need > ctx->deflate_ws_cap) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (ctx->deflate_ws)
+            HIP_TRY(hipFree(ctx->deflate_ws));
+        ctx->deflate_ws = nullptr;
+        ctx->deflate_ws_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->deflate_ws, need));
+        ctx->deflate_ws_cap = need;
+    }
+    job.t.hist = reinterpret_cast<uint32_t *>(ctx->deflate_ws);
+    job.t.books = reinterpret_cast<uint8_t *>(ctx->deflate_ws) + (size_t)nblocks * kHistWords * 4;
+
+    static_assert(sizeof(SharedFA) <= 160 * 1024, "fused statistics pass must fit LDS");
+    static_assert(sizeof(SharedFC<true>) <= 80 * 1024, "two small-stream fused emit workgroups per CU");
+    static_assert(sizeof(SharedFC<false>) <= 160 * 1024, "fused emit pass must fit LDS");
+    if (!ctx->fused_ready) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_stats_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SharedFA)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_emit_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SharedFC<true>)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_emit_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SharedFC<false>)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(deflate_codes_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(sizeof(Work) * kBuildThreads)));
+        ctx->fused_ready = true;
+    }
+    hipStream_t s = as_stream(ctx, stream);
+    HIP_TRY(hipMemsetAsync(cursor_dev, 0, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(fused_stats_kernel, dim3(positions), dim3(kTile), sizeof(SharedFA), s, job);
+    if (ctx->deflate_wave_codes)
+        hipLaunchKernelGGL(deflate_codes_wave_kernel,
+                           dim3(((uint32_t)nblocks + kWavesPerBlock - 1) / kWavesPerBlock),
+                           dim3(64 * kWavesPerBlock), 0, s, job.t);
+    else
+        hipLaunchKernelGGL(deflate_codes_kernel, dim3(((uint32_t)nblocks + kBuildThreads - 1) / kBuildThreads),
+                           dim3(kBuildThreads), sizeof(Work) * kBuildThreads, s, job.t);
+    hipLaunchKernelGGL(fused_emit_kernel<true>, dim3(positions), dim3(kTile), sizeof(SharedFC<true>), s, job);
+    hipLaunchKernelGGL(fused_emit_kernel<false>, dim3(positions), dim3(kTile), sizeof(SharedFC<false>), s, job);
     HIP_TRY(hipGetLastError());
     return GCN10_OK;
 }

@@ -837,6 +837,8 @@ void gcn10_gpu_destroy(gcn10_gpu_ctx *ctx)
         (void)hipFree(ctx->d_hx);
     if (ctx->deflate_ws)
         (void)hipFree(ctx->deflate_ws);
+    if (ctx->d_class_of)
+        (void)hipFree(ctx->d_class_of);
     delete ctx;
 }
 
@@ -1089,6 +1091,56 @@ int gcn10_gpu_set_tables(gcn10_gpu_ctx *ctx, const int *tables, int n_tables)
     HIP_TRY(hipMemcpy(ctx->d_lut16, img16, sizeof img16, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_lut1, img1, sizeof img1, hipMemcpyHostToDevice));
     ctx->n_tables = n_tables;
+
+    // ---- pixel classes for the fused tile encoder (gcn10_deflate.hip): two pixels are in one
+    // class iff all 18 rasters agree on them, i.e. iff their (soil code, landcover) pairs have
+    // the same 18-vector of CN values.  Class 0 is the zero padding outside the raster.
+    {
+        static thread_local uint8_t class_of[gcn10::kClassCodes * 256];
+        static thread_local uint8_t class_val[GCN10_N_RASTERS * 256];
+        static thread_local uint8_t vecs[257][GCN10_N_RASTERS];
+        int n_classes = 1;
+        memset(vecs[0], 0, sizeof vecs[0]);
+        memset(class_val, 0, sizeof class_val);
+        bool fits = true;
+        for (int cc = 0; cc < gcn10::kClassCodes && fits; cc++) {
+            const int sd = cc / 6, su = cc % 6;
+            for (int lc = 0; lc < 256 && fits; lc++) {
+                uint8_t v[GCN10_N_RASTERS];
+                for (int r = 0; r < GCN10_N_RASTERS; r++) {
+                    const int sgrp = r < 9 ? sd : su;
+                    const int k = r % 9;
+                    v[r] = (sgrp < 5 && k < n_tables) ? img16[sgrp * kPlane16 + lc * 16 + k]
+                                                      : (uint8_t)GCN10_NODATA;
+                }
+                int id = -1;
+                for (int c = 1; c < n_classes; c++)
+                    if (memcmp(vecs[c], v, sizeof v) == 0) {
+                        id = c;
+                        break;
+                    }
+                if (id < 0) {
+                    if (n_classes == 256) {
+                        fits = false;
+                        break;
+                    }
+                    id = n_classes++;
+                    memcpy(vecs[id], v, sizeof v);
+                    for (int r = 0; r < GCN10_N_RASTERS; r++)
+                        class_val[r * 256 + id] = v[r];
+                }
+                class_of[cc * 256 + lc] = (uint8_t)id;
+            }
+        }
+        ctx->n_classes = fits ? n_classes : 0;      // 0: more than 256 classes, fused encoder unavailable
+        if (fits) {
+            if (!ctx->d_class_of)
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_class_of), sizeof class_of + sizeof class_val));
+            HIP_TRY(hipMemcpy(ctx->d_class_of, class_of, sizeof class_of, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(ctx->d_class_of + sizeof class_of, class_val, sizeof class_val,
+                              hipMemcpyHostToDevice));
+        }
+    }
     return GCN10_OK;
 }
 

@@ -26,6 +26,10 @@ hipStream_t as_stream(gcn10_gpu_ctx *ctx, gcn10_stream_t s);
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// soil code byte of the hx workspace: drained plane | undrained plane << 4, planes 0..5;
+// compact index = drained * 6 + undrained
+constexpr int kClassCodes = 36;
+
 }  // namespace gcn10
 
 struct gcn10_gpu_ctx {
@@ -51,7 +55,10 @@ struct gcn10_gpu_ctx {
     int prefetch = -1;      // loads of the next trip issued before the current one is consumed:
                             // -1 = per kernel default (on for all-tables, off for single-table)
     hipEvent_t time_start = nullptr, time_stop = nullptr;  // one-shot: bracket the next strip kernel
+    uint8_t *d_class_of = nullptr;  // [36][256] pixel class of (soil code, landcover), then [18][256] values
+    int n_classes = 0;              // 0: not available (set_tables not called, or > 256 classes)
     int deflate_wave_codes = 1;     // pass B of the tile encoder: 1 = one wave per tile, 0 = one thread
+    bool fused_ready = false;
     bool deflate_ready = false;     // LDS attributes of the tile encoder set on this device
     void *deflate_ws = nullptr;     // per-tile statistics + code books of the tile encoder
     size_t deflate_ws_cap = 0;

@@ -44,7 +44,7 @@ int gcn10_config_parse(const char *path, gcn10_config *cfg, char *err, size_t er
     FILE *f;
 
     memset(cfg, 0, sizeof *cfg);
-    cfg->gpu_deflate = 1;
+    cfg->gpu_deflate = 2;
     f = fopen(path, "r");
     if (!f) {
         snprintf(err, errcap, "cannot open config '%s'", path);     /* src/config.c:52 */
@@ -87,7 +87,7 @@ int gcn10_config_parse(const char *path, gcn10_config *cfg, char *err, size_t er
         else if (!strcmp(key, "deflate_level"))
             cfg->deflate_level = atoi(val);
         else if (!strcmp(key, "gpu_deflate"))
-            cfg->gpu_deflate = atoi(val) != 0;
+            cfg->gpu_deflate = atoi(val) < 0 ? 0 : (atoi(val) > 2 ? 2 : atoi(val));
         if (rc != 0) {
             fclose(f);
             snprintf(err, errcap, "malloc failed for %s", key);     /* src/config.c:71 */

@@ -61,6 +61,9 @@ struct gcn10_gpu_api {
     int (*cn_strip)(gcn10_gpu_ctx *, const uint8_t *, int, int, const int32_t *, unsigned, unsigned,
                     uint8_t *const[GCN10_N_RASTERS], gcn10_stream_t);
     int (*pci_bus_id)(int, char *, size_t);
+    int (*deflate_fused_available)(gcn10_gpu_ctx *);
+    int (*deflate_fused_strip)(gcn10_gpu_ctx *, const uint8_t *, int, int, const int32_t *, unsigned, unsigned,
+                               uint8_t *, size_t, uint32_t *, unsigned long long *, gcn10_stream_t);
     size_t (*deflate_arena_bound)(int, int, int);
     int (*deflate_strip)(gcn10_gpu_ctx *, const uint8_t *const *, int, int, int, uint8_t *, size_t,
                          uint32_t *, unsigned long long *, gcn10_stream_t);

@@ -80,6 +80,7 @@ struct worker {
     int32_t *d_ci, *d_cj;
     size_t ci_cap, cj_cap;
     atomic_bool failed;                     /* a sink job of the current block failed */
+    bool fused;                             /* this worker's tables allow the fused encoder */
     int blocks_done;
     double busy_seconds;
     double t_read, t_gpu_wait, t_sink_wait, t_setup;   /* where the worker thread's time goes */
@@ -102,6 +103,7 @@ struct run {
     int deflate_level;
     bool null_sink;                         /* GCN10_SINK=null: no compression, no files */
     bool gpu_deflate;                       /* tiles are encoded on the GPU */
+    bool fused;                             /* ... straight from landcover + soil (no CN rasters in HBM) */
     int n_devices;                          /* visible GPUs; worker i uses device i % n_devices */
     int outer_rank, outer_size;             /* this process among the processes of an mpirun / srun */
 };
@@ -374,7 +376,8 @@ static int ensure_strip_buffers(struct worker *w, int W)
         for (int k = 0; k < GCN10_N_RASTERS; k++) {
             if (!w->run->gpu_deflate)
                 GPU_TRY(w, g->host_alloc(w->ctx, px, (void **)&b->h_out[k]));
-            GPU_TRY(w, g->malloc(w->ctx, px, (void **)&b->d_out[k]));
+            if (!w->fused)
+                GPU_TRY(w, g->malloc(w->ctx, px, (void **)&b->d_out[k]));
         }
         if (w->run->gpu_deflate) {
             size_t tiles = (size_t)((W + TILE - 1) / TILE) * (size_t)(w->run->strip_rows / TILE);
@@ -393,10 +396,12 @@ static int ensure_strip_buffers(struct worker *w, int W)
             GPU_TRY(w, g->host_alloc(w->ctx, tiles * GCN10_N_RASTERS * 8, (void **)&b->h_table));
             GPU_TRY(w, g->malloc(w->ctx, 8, (void **)&b->d_cursor));
             GPU_TRY(w, g->host_alloc(w->ctx, 8, (void **)&b->h_cursor));
-            GPU_TRY(w, g->malloc(w->ctx, GCN10_N_RASTERS * sizeof(void *), (void **)&b->d_ptrs));
-            GPU_TRY(w, g->memcpy_h2d(w->ctx, (void *)b->d_ptrs, b->d_out, GCN10_N_RASTERS * sizeof(void *),
-                                     w->s_kernel));
-            GPU_TRY(w, g->stream_sync(w->ctx, w->s_kernel));
+            if (!w->fused) {
+                GPU_TRY(w, g->malloc(w->ctx, GCN10_N_RASTERS * sizeof(void *), (void **)&b->d_ptrs));
+                GPU_TRY(w, g->memcpy_h2d(w->ctx, (void *)b->d_ptrs, b->d_out, GCN10_N_RASTERS * sizeof(void *),
+                                         w->s_kernel));
+                GPU_TRY(w, g->stream_sync(w->ctx, w->s_kernel));
+            }
         }
     }
     w->buf_px = px;
@@ -575,12 +580,30 @@ static int process_block(struct worker *w, int block_id)
             goto gpu_fail;
         for (int k = 0; k < GCN10_N_RASTERS; k++)
             outs[k] = b->d_out[k];
-        if (g->cn_strip(w->ctx, b->d_esa, W, rows, w->d_cj + y0,
-                        GCN10_COND_DRAINED | GCN10_COND_UNDRAINED, 0x1ffu, outs, w->s_kernel) != 0 ||
-            g->event_record(w->ctx, b->ev_kernel, w->s_kernel) != 0 ||
-            g->stream_wait_event(w->ctx, w->s_d2h, b->ev_kernel) != 0)
+        if (w->fused) {
+            /* landcover + soil -> 18 x compressed tiles in one device pass, no CN strip in HBM */
+            int across = (W + TILE - 1) / TILE, down = (rows + TILE - 1) / TILE;
+
+            if (g->deflate_fused_strip(w->ctx, b->d_esa, W, rows, w->d_cj + y0,
+                                       GCN10_COND_DRAINED | GCN10_COND_UNDRAINED, 0x1ffu, b->d_arena,
+                                       b->arena_cap, b->d_table, b->d_cursor, w->s_kernel) != 0 ||
+                g->event_record(w->ctx, b->ev_kernel, w->s_kernel) != 0 ||
+                g->stream_wait_event(w->ctx, w->s_d2h, b->ev_kernel) != 0 ||
+                g->memcpy_d2h(w->ctx, b->h_cursor, b->d_cursor, 8, w->s_d2h) != 0 ||
+                g->memcpy_d2h(w->ctx, b->h_table, b->d_table,
+                              (size_t)across * down * GCN10_N_RASTERS * 8, w->s_d2h) != 0 ||
+                g->event_record(w->ctx, b->ev_meta, w->s_d2h) != 0)
+                goto gpu_fail;
+        }
+        else if (g->cn_strip(w->ctx, b->d_esa, W, rows, w->d_cj + y0,
+                             GCN10_COND_DRAINED | GCN10_COND_UNDRAINED, 0x1ffu, outs, w->s_kernel) != 0 ||
+                 g->event_record(w->ctx, b->ev_kernel, w->s_kernel) != 0 ||
+                 g->stream_wait_event(w->ctx, w->s_d2h, b->ev_kernel) != 0)
             goto gpu_fail;
-        if (r->gpu_deflate) {
+        if (w->fused) {
+            /* issued above */
+        }
+        else if (r->gpu_deflate) {
             /* encode the 18 strips where they are; only sizes, offsets and (later, in
              * drain_strip) the compressed bytes go to the host */
             int across = (W + TILE - 1) / TILE, down = (rows + TILE - 1) / TILE;
@@ -780,6 +803,10 @@ static int worker_setup(struct worker *w)
         return -1;
     }
     GPU_TRY(w, g->set_tables(w->ctx, &r->tables[0][0][0], 9));
+    w->fused = r->fused && g->deflate_fused_available(w->ctx) == 1;
+    if (r->fused && !w->fused)
+        wlog(w, "INFO", false, "the lookup tables define more than 256 pixel classes: "
+                               "per-raster GPU encoding instead of the fused encoder");
     GPU_TRY(w, g->stream_create(w->ctx, &w->s_h2d));
     GPU_TRY(w, g->stream_create(w->ctx, &w->s_kernel));
     GPU_TRY(w, g->stream_create(w->ctx, &w->s_d2h));
@@ -905,6 +932,7 @@ int gcn10_run(const gcn10_run_options *opt)
     r->strip_rows = (r->strip_rows + TILE - 1) / TILE * TILE;
     r->deflate_level = r->cfg.deflate_level;
     r->gpu_deflate = r->cfg.gpu_deflate != 0;
+    r->fused = r->cfg.gpu_deflate == 2;
 
     /* GPUs: one worker ("rank") each */
     r->gpu = gcn10_gpu_api_get(err, sizeof err);
@@ -1088,7 +1116,8 @@ int gcn10_run(const gcn10_run_options *opt)
         snprintf(msg, sizeof msg, "timing: %d blocks, %.3f s wall, %d gpu worker(s)%s%s; worker seconds: "
                  "in blocks %.3f, reading landcover %.3f, waiting for gpu %.3f, waiting for sink %.3f",
                  done_blocks, now_seconds() - t_start, r->n_workers, r->null_sink ? ", null sink" : "",
-                 r->gpu_deflate ? ", gpu deflate" : ", host zlib", busy, rd, gw, sw);
+                 r->gpu_deflate ? (r->fused ? ", fused gpu deflate" : ", gpu deflate") : ", host zlib", busy, rd, gw,
+                 sw);
         gcn10_log_message(log0, "INFO", msg, false);
     }
     exit_code = atomic_load(&r->fatal) ? 1 : 0;

@@ -39,7 +39,8 @@ ABI_SYMBOLS = (
     "gcn10_gpu_calculate_cn", "gcn10_gpu_prepare_tile", "gcn10_gpu_cn_strip",
     "gcn10_gpu_strip_algorithmic_bytes", "gcn10_gpu_last_kernel_name", "gcn10_gpu_set_option",
     "gcn10_gpu_deflate_arena_bound", "gcn10_gpu_deflate_strip", "gcn10_gpu_time_next_strip",
-    "gcn10_gpu_pci_bus_id",
+    "gcn10_gpu_pci_bus_id", "gcn10_gpu_deflate_fused_strip",
+    "gcn10_gpu_deflate_fused_available",
 )
 
 
@@ -93,6 +94,8 @@ def lib():
             "gcn10_gpu_set_option": (i, [vp, C.c_char_p, i]),
             "gcn10_gpu_time_next_strip": (i, [vp, vp, vp]),
             "gcn10_gpu_pci_bus_id": (i, [i, C.c_char_p, sz]),
+            "gcn10_gpu_deflate_fused_strip": (i, [vp, vp, i, i, vp, u, u, vp, sz, vp, vp, vp]),
+            "gcn10_gpu_deflate_fused_available": (i, [vp]),
             "gcn10_gpu_deflate_arena_bound": (sz, [i, i, i]),
             "gcn10_gpu_deflate_strip": (i, [vp, vp, i, i, i, vp, sz, vp, vp, vp]),
         }
@@ -314,6 +317,28 @@ class Engine:
             data = self.download(arena.ptr, (min(used, cap),), stream=stream)
         finally:
             for b in (ptrs, arena, table, cursor):
+                b.close()
+        return data, tab, used
+
+    def deflate_fused(self, esa_d: int, W: int, rows: int, cj_d: int, cond_mask: int = 3,
+                      table_mask: int = ALL_TABLES, stream=None):
+        """Encoded tiles of the selected rasters straight from landcover + prepared soil
+        (gcn10_gpu_deflate_fused_strip).  Returns (arena bytes, table uint32[n, down, across, 2], used)."""
+        n = bin(cond_mask & 3).count("1") * bin(table_mask & ALL_TABLES).count("1")
+        across, down = (W + 255) // 256, (rows + 255) // 256
+        cap = int(lib().gcn10_gpu_deflate_arena_bound(W, rows, n))
+        arena = self.alloc(cap)
+        table = self.alloc(n * across * down * 8)
+        cursor = self.alloc(8)
+        try:
+            self._chk(lib().gcn10_gpu_deflate_fused_strip(self._ctx, esa_d, W, rows, cj_d, cond_mask,
+                                                          table_mask, arena.ptr, cap, table.ptr, cursor.ptr,
+                                                          stream), "gcn10_gpu_deflate_fused_strip")
+            used = int(self.download(cursor.ptr, (1,), dtype=np.uint64, stream=stream)[0])
+            tab = self.download(table.ptr, (n, down, across, 2), dtype=np.uint32, stream=stream)
+            data = self.download(arena.ptr, (min(used, cap),), stream=stream)
+        finally:
+            for b in (arena, table, cursor):
                 b.close()
         return data, tab, used
 

@@ -187,6 +187,19 @@ int gcn10_gpu_deflate_strip(gcn10_gpu_ctx *ctx, const uint8_t *const *rasters_de
                             size_t arena_cap, uint32_t *table_dev,
                             unsigned long long *cursor_dev, gcn10_stream_t stream);
 
+/* The same encoding WITHOUT materialising the CN rasters: the strip's landcover and the
+ * block's x-expanded soil (gcn10_gpu_prepare_tile) are reduced to pixel classes once per
+ * tile position, tokenised once, and the selected rasters' streams are produced from that
+ * (src/cn.c:236-290 and the zlib of src/raster.c:204-219 in one device pass; no CN raster
+ * is written to or read from HBM).  Stream r' of the table is the r'-th selected raster in
+ * ascending raster order (cond*9 + hc*3 + arc).  Needs the tables to define at most 256
+ * distinct 18-vectors (GCN10_E_STATE otherwise; the shipped tables define about 110). */
+int gcn10_gpu_deflate_fused_available(gcn10_gpu_ctx *ctx);     /* 1 after set_tables if <= 256 classes */
+int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, int rows,
+                                  const int32_t *cj, unsigned cond_mask, unsigned table_mask,
+                                  uint8_t *arena_dev, size_t arena_cap, uint32_t *table_dev,
+                                  unsigned long long *cursor_dev, gcn10_stream_t stream);
+
 /* Launch-shape knobs of the strip kernels, for tuning runs; results never
  * depend on them.  Names: "grid_blocks_per_cu" (1..64), "ilp16" (0 = by raster count | 1 | 2),
  * "ilp1" (1|2|4), "nontemporal" (0|1), "xcd_slabs" (0|1), "prefetch" (-1 = per-kernel default | 0 | 1), "deflate_wave_codes" (0|1: code

@@ -95,9 +95,10 @@ typedef struct gcn10_config {
     int io_threads;         /* "io_threads": tile compression threads, 0 = auto    */
     int deflate_level;      /* "deflate_level": zlib level 1..9, 0 = zlib default 6 */
     char *esa_tile_dir;     /* "esa_tile_dir": local mirror of /vsicurl/ VRT sources */
-    int gpu_deflate;        /* "gpu_deflate": 1 (default) tiles are DEFLATE-encoded on the
-                               GPU and only compressed bytes cross PCIe; 0 = raw strips
-                               are copied back and compressed by host zlib threads */
+    int gpu_deflate;        /* "gpu_deflate": 2 (default) fused: tiles are DEFLATE-encoded on the
+                               GPU straight from landcover + soil, no CN raster in HBM;
+                               1 = CN strips in HBM, then encoded on the GPU per raster;
+                               0 = raw strips are copied back, host zlib threads encode */
 } gcn10_config;
 
 /* Returns 0; -1 cannot open (message in err); -2 a required key is missing

@@ -78,7 +78,7 @@ def test_no_gpu_means_no_run(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gpu_deflate", [1, 0], ids=["gpu-deflate", "host-zlib"])
+@pytest.mark.parametrize("gpu_deflate", [2, 1, 0], ids=["fused-gpu-deflate", "gpu-deflate", "host-zlib"])
 def test_blocks_equal_oracle_and_reference_conventions(tmp_path, tables, gpu_deflate):
     esa, soil = _world(tmp_path, extra_cfg="gpu_deflate=%d\n" % gpu_deflate)
     (tmp_path / "ids.txt").write_text("101 102\n103\n104 999\n")

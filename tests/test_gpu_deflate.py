@@ -113,3 +113,95 @@ def test_wave_and_thread_code_construction_agree(engine, kind):
     engine.set_option("deflate_wave_codes", 1)
     buf.close()
     assert streams[0] == streams[1]
+
+
+# ---- fused tile encoder: landcover + soil -> zlib streams, no CN raster in between -----------
+
+def _fused_case(engine, tables, H, W, seed, cond_mask=3, table_mask=0x1FF, nasty=True, coherent=True,
+                esa_override=None):
+    from gcn10_amd import host
+    from oracle import cn_oracle_c as oc
+    from tests.util import make_block
+    esa, gt, coarse, sgt = make_block(seed, H, W, H // 25 + 2, W // 25 + 2, nasty=nasty)
+    if coherent:        # patchy landcover so that matches exist
+        small = esa[::8, ::8]
+        esa = np.ascontiguousarray(np.repeat(np.repeat(small, 8, axis=0), 8, axis=1)[:H, :W])
+    if esa_override is not None:
+        esa = esa_override
+    hsy, hsx = coarse.shape
+    ci, cj = host.build_index_maps(gt, sgt, W, H, hsx, hsy)
+    engine.set_tables(tables)
+    bufs = [engine.upload(a) for a in (esa, coarse, ci, cj)]
+    engine.prepare_tile(bufs[1].ptr, hsx, hsy, bufs[2].ptr, W)
+    data, table, used = engine.deflate_fused(bufs[0].ptr, W, H, bufs[3].ptr, cond_mask, table_mask)
+    for b in bufs:
+        b.close()
+    want = oc.process_block_mem(esa, gt, coarse, sgt, tables, cond_mask=cond_mask, table_mask=table_mask)
+    sel = [r for r in range(18) if (cond_mask >> (r // 9)) & 1 and (table_mask >> (r % 9)) & 1]
+    across, down = (W + 255) // 256, (H + 255) // 256
+    assert table.shape == (len(sel), down, across, 2)
+    total = 0
+    for j, r in enumerate(sel):
+        for ty in range(down):
+            for tx in range(across):
+                off, size = int(table[j, ty, tx, 0]), int(table[j, ty, tx, 1])
+                assert off != 0xFFFFFFFF and 0 < size <= 65552 and off + size <= used
+                exp = np.zeros((256, 256), np.uint8)
+                part = want[r][ty * 256:(ty + 1) * 256, tx * 256:(tx + 1) * 256]
+                exp[:part.shape[0], :part.shape[1]] = part
+                assert zlib.decompress(data[off:off + size].tobytes()) == exp.tobytes(), (r, ty, tx)
+                total += size
+    return total, want, sel
+
+
+@pytest.mark.parametrize("shape", [(256, 256), (300, 700), (513, 1025), (1, 1), (700, 36001 // 40)])
+def test_fused_encoder_streams_inflate_to_the_oracle_rasters(engine, tables, shape):
+    H, W = shape
+    _fused_case(engine, tables, H, W, seed=H + W)
+
+
+def test_fused_encoder_noise_and_subsets(engine, tables):
+    # i.i.d. landcover: mostly literals, big streams (the 64 KB-image variant)
+    _fused_case(engine, tables, 300, 520, seed=5, coherent=False)
+    _fused_case(engine, tables, 300, 520, seed=6, cond_mask=2, table_mask=0x0A1)
+    _fused_case(engine, tables, 260, 260, seed=7, cond_mask=1, table_mask=0x100)
+
+
+def test_fused_encoder_awkward_tables(engine):
+    from tests.util import random_tables
+    t = random_tables(77, 9)
+    t[:, 6:, :] = 255           # 6 live classes x 36 soil-code pairs: under 256 distinct 18-vectors
+    from gcn10_amd import host
+    H, W = 300, 300
+    rng = np.random.default_rng(8)
+    # landcover from the live classes (and a few dead ones), patchy
+    small = rng.integers(0, 9, size=((H + 7) // 8, (W + 7) // 8), dtype=np.uint8)
+    _fused_case(engine, t, H, W, seed=8, esa_override=np.ascontiguousarray(
+        np.repeat(np.repeat(small, 8, axis=0), 8, axis=1)[:H, :W]))
+
+
+def test_fused_vs_unfused_size(engine, tables):
+    """The class-based match structure costs little compression against per-raster parsing."""
+    H, W = 512, 768
+    fused, want, sel = _fused_case(engine, tables, H, W, seed=9)
+    bufs = [engine.upload(want[r]) for r in sel]
+    data, table, used = engine.deflate_rasters([b.ptr for b in bufs], W, H)
+    for b in bufs:
+        b.close()
+    unfused = int(table[..., 1].sum())
+    print("fused %d B, per-raster %d B, ratio %.3f" % (fused, unfused, fused / unfused))
+    assert fused <= 1.10 * unfused
+
+
+def test_fused_needs_at_most_256_classes(engine):
+    from gcn10_amd import gpu
+    from tests.util import random_tables
+    engine.set_tables(random_tables(3, 9))              # every (class, soil) pair its own vector
+    esa = engine.upload(np.zeros((16, 16), np.uint8))
+    coarse = engine.upload(np.zeros((1, 1), np.uint8))
+    ci = engine.upload(np.zeros(16, np.int32))
+    engine.prepare_tile(coarse.ptr, 1, 1, ci.ptr, 16)
+    with pytest.raises(gpu.Gcn10GpuError, match="256 pixel classes"):
+        engine.deflate_fused(esa.ptr, 16, 16, ci.ptr)
+    for b in (esa, coarse, ci):
+        b.close()

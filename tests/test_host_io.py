@@ -27,7 +27,7 @@ def test_config_reference_file_shape(tmp_path):
     assert c["hysogs_data_path"] == "../../hsg/HYSOGs250m_4326_lzw.tif"
     assert c["esa_data_path"] == "../../landcover/esa_worldcover_2021.vrt"     # trimmed
     assert c["log_dir"] == "logs2/"                                            # last one wins
-    assert c["gpus"] == 0 and c["esa_tile_dir"] is None and c["gpu_deflate"] == 1
+    assert c["gpus"] == 0 and c["esa_tile_dir"] is None and c["gpu_deflate"] == 2
 
 
 def test_config_optional_keys_and_errors(tmp_path):

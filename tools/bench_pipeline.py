@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--reuse", action="store_true", help="reuse the world already in --workdir")
     ap.add_argument("--keep", action="store_true", help="do not delete --workdir at the end")
     ap.add_argument("--deflate-level", type=int, default=0)
-    ap.add_argument("--gpu-deflate", type=int, default=1)
+    ap.add_argument("--gpu-deflate", type=int, default=2)
     ap.add_argument("--workers-per-gpu", type=int, default=0)
     ap.add_argument("--real-vrt-pixel", action="store_true",
                     help="use the shipped VRT's pixel size 8.3333333333330430e-05: 3-degree blocks become "
