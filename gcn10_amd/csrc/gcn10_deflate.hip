@@ -1272,11 +1272,15 @@ __global__ __launch_bounds__(kTile) void deflate_emit_kernel(const TileJob job)
 // little compression.  Passes: F-A statistics per tile position -> B code construction
 // per (raster, tile), unchanged -> F-C emission per tile position, looping over rasters.
 // ------------------------------------------------------------------------
+constexpr int kGroup = 6;            // rasters emitted by one workgroup of pass F-C
+
 struct FusedJob {
     const uint8_t *esa;
     const uint8_t *hx;
     const int32_t *cj;
     const uint8_t *class_of;        // [36][256]; class_val [18][256] follows
+    uint8_t *tok;                   // [positions][kTileBytes] tokenised class tiles (F-A -> F-C)
+    unsigned long long *tok_start;  // [positions][kTile][4]   where their match tokens start
     uint32_t hx_stride, hx_rows;
     uint32_t n_sel;                 // selected rasters, ascending
     uint8_t sel[GCN10_N_RASTERS];
@@ -1288,57 +1292,141 @@ __device__ __forceinline__ uint32_t compact_code(uint32_t code)
     return (code & 15u) * 6u + (code >> 4);
 }
 
-// Class ids of one tile position into LDS (row stride kRowStride); class 0 outside the raster.
+// Class ids of pixels (x..x+3, y) of the strip, one per byte; class 0 outside the raster.
+__device__ __forceinline__ uint32_t class_pixels4(const FusedJob &job, uint32_t x, uint32_t y,
+                                                  const uint8_t *class_of_lds)
+{
+    typedef uint32_t u32_u __attribute__((aligned(1)));
+    const uint32_t W = job.t.W;
+    uint32_t out = 0;
+    if (y < job.t.rows && x < W) {
+        uint32_t srow = (uint32_t)job.cj[y];
+        srow = srow < job.hx_rows ? srow : job.hx_rows - 1u;
+        const uint8_t *pe = job.esa + (size_t)y * W + x;
+        // hx rows are padded by >= 16 bytes past W: a 4-byte read starting below W is safe
+        const uint32_t c4 = *reinterpret_cast<const u32_u *>(job.hx + (size_t)srow * job.hx_stride + x);
+        uint32_t e4 = 0;
+        if (x + 4u <= W) {
+            e4 = *reinterpret_cast<const u32_u *>(pe);
+        }
+        else {
+            for (uint32_t k = 0; x + k < W; k++)
+                e4 |= (uint32_t)pe[k] << (8 * k);
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            if (x + q < W) {
+                const uint32_t lc = (e4 >> (8 * q)) & 0xffu;
+                const uint32_t cc = compact_code((c4 >> (8 * q)) & 0xffu);
+                out |= (uint32_t)class_of_lds[cc * 256u + lc] << (8 * q);
+            }
+        }
+    }
+    return out;
+}
+
+// Class ids of one tile position into LDS (row stride kRowStride).
 __device__ __forceinline__ void load_class_tile(const FusedJob &job, uint32_t tx, uint32_t ty,
                                                 const uint8_t *class_of_lds, uint8_t *tile, int t)
 {
-    typedef uint32_t u32_u __attribute__((aligned(1)));
-    const uint32_t W = job.t.W, rows = job.t.rows;
     const uint32_t x = tx * kTile + (uint32_t)(t & 63) * 4u;
     uint32_t *dst = reinterpret_cast<uint32_t *>(tile) + (t & 63);
 #pragma unroll 4
     for (int i = 0; i < kTile / 4; i++) {
         const int r = i * 4 + (t >> 6);
-        const uint32_t y = ty * kTile + (uint32_t)r;
-        uint32_t out = 0;
-        if (y < rows && x < W) {
-            uint32_t srow = (uint32_t)job.cj[y];
-            srow = srow < job.hx_rows ? srow : job.hx_rows - 1u;
-            const uint8_t *pe = job.esa + (size_t)y * W + x;
-            // hx rows are padded by >= 16 bytes past W: a 4-byte read starting below W is safe
-            const uint32_t c4 = *reinterpret_cast<const u32_u *>(job.hx + (size_t)srow * job.hx_stride + x);
-            uint32_t e4 = 0;
-            if (x + 4u <= W) {
-                e4 = *reinterpret_cast<const u32_u *>(pe);
-            }
-            else {
-                for (uint32_t k = 0; x + k < W; k++)
-                    e4 |= (uint32_t)pe[k] << (8 * k);
-            }
-#pragma unroll
-            for (uint32_t q = 0; q < 4; q++) {
-                if (x + q < W) {
-                    const uint32_t lc = (e4 >> (8 * q)) & 0xffu;
-                    const uint32_t cc = compact_code((c4 >> (8 * q)) & 0xffu);
-                    out |= (uint32_t)class_of_lds[cc * 256u + lc] << (8 * q);
-                }
-            }
-        }
-        dst[r * (kRowStride / 4)] = out;
+        dst[r * (kRowStride / 4)] = class_pixels4(job, x, ty * kTile + (uint32_t)r, class_of_lds);
     }
+}
+
+__device__ __forceinline__ void set_bit(unsigned long long (&m)[4], int x)
+{
+    const unsigned long long b = 1ull << (x & 63);
+    const int w = x >> 6;
+    m[0] |= w == 0 ? b : 0ull;
+    m[1] |= w == 1 ? b : 0ull;
+    m[2] |= w == 2 ? b : 0ull;
+    m[3] |= w == 3 ? b : 0ull;
+}
+
+// next position >= x with a set bit (256 if none)
+__device__ __forceinline__ int next_set(const unsigned long long (&m)[4], int x)
+{
+    for (int pos = x; pos < kTile;) {
+        const int b = pos & 63;
+        const unsigned long long v = pick(m, pos >> 6) >> b;
+        if (v)
+            return pos + __builtin_ctzll(v);
+        pos += 64 - b;
+    }
+    return kTile;
+}
+
+// The greedy parse of parse_row(), done once per tile position and kept: statistics are
+// counted, and the row is rewritten IN PLACE as its token stream.  A literal stays the byte
+// it was (a class id); a match of length len at x (it covers >= 3 bytes) becomes
+//   row[x]   = length code (0..28) | 0x80 if its distance is 256
+//   row[x+1] = value of the length's extra bits | number of extra bits << 5
+//   row[x+2] = len - 3
+// and bit x of `start` is set.  Every mask of the tile must have been computed before.
+__device__ __forceinline__ void tokenise_row(uint8_t *tile, int t, const RowMasks &m, uint32_t *lit_hist,
+                                             uint32_t *dist_hist, unsigned long long (&start)[4])
+{
+    uint8_t *row = tile + t * kRowStride;
+    int x = 0;
+    start[0] = start[1] = start[2] = start[3] = 0ull;
+    while (x < kTile) {
+        const int cand = next_candidate(m, x);
+        for (; x < cand; x++)
+            atomicAdd(&lit_hist[row[x]], 1u);
+        if (x >= kTile)
+            break;
+        const int l1 = run_from(m.near_, x);
+        const int l256 = run_from(m.far_, x);
+        const bool far = l256 > l1;                 // tie: distance 1 (no extra bits)
+        const int len = far ? l256 : l1;
+        if (len >= 3) {
+            const int lc = length_code(len);
+            const int ne = (lc < 8 || lc == 28) ? 0 : (lc - 4) >> 2;
+            atomicAdd(&lit_hist[257 + lc], 1u);
+            atomicAdd(&dist_hist[far ? 1 : 0], 1u);
+            row[x] = (uint8_t)(lc | (far ? 0x80 : 0));
+            row[x + 1] = (uint8_t)((len - kLenBase[lc]) | (ne << 5));
+            row[x + 2] = (uint8_t)(len - 3);
+            set_bit(start, x);
+            x += len;
+        }
+        else {
+            atomicAdd(&lit_hist[row[x]], 1u);
+            x++;
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_sum64(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off, 64);
+    return v;
 }
 
 struct SharedFA {
     uint8_t tile[kTile * kRowStride];
-    uint8_t class_of[gcn10::kClassCodes * 256];
-    uint8_t class_val[GCN10_N_RASTERS * 256];
-    uint32_t lit_hist[288];         // literals by class, match length symbols at 257..
-    uint32_t dist_hist[2];
-    uint32_t n_c[256], w_c[256];    // pixels per class, sum of their Adler position weights
-    uint32_t H[GCN10_N_RASTERS][288];
-    uint32_t adler[GCN10_N_RASTERS];
+    union {
+        uint8_t class_of[gcn10::kClassCodes * 256];     // while the tile is built
+        struct {
+            uint32_t lit_hist[288];     // literals by class, match length symbols at 257..
+            uint32_t dist_hist[2];
+            uint32_t n_c[256], w_c[256];                // pixels per class, sum of their Adler weights
+            uint32_t H[kGroup][256];                    // literal counts by VALUE, kGroup rasters at a time
+            uint32_t s1[GCN10_N_RASTERS], s2[GCN10_N_RASTERS];
+        } a;
+    };
 };
 
+// pass F-A: one workgroup per tile position.  Classes -> tokens + statistics of the class
+// stream -> per raster: value statistics and Adler-32 (from per-class pixel counts and
+// position weights, no raster byte is ever formed).
 __global__ __launch_bounds__(kTile) void fused_stats_kernel(const FusedJob job)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1347,20 +1435,26 @@ __global__ __launch_bounds__(kTile) void fused_stats_kernel(const FusedJob job)
     const uint32_t tiles = job.t.across * job.t.down;
     const uint32_t tix = blockIdx.x;
     const uint32_t ty = tix / job.t.across, tx = tix - ty * job.t.across;
+    const uint8_t *class_val = job.class_of + gcn10::kClassCodes * 256;
 
-    for (int i = t; i < (gcn10::kClassCodes * 256 + GCN10_N_RASTERS * 256) / 4; i += kTile)
+    for (int i = t; i < gcn10::kClassCodes * 256 / 4; i += kTile)
         reinterpret_cast<uint32_t *>(sh.class_of)[i] = reinterpret_cast<const uint32_t *>(job.class_of)[i];
-    for (int i = t; i < 288; i += kTile)
-        sh.lit_hist[i] = 0;
-    if (t < 2)
-        sh.dist_hist[t] = 0;
-    sh.n_c[t] = 0;
-    sh.w_c[t] = 0;
-    for (int i = t; i < GCN10_N_RASTERS * 288; i += kTile)
-        (&sh.H[0][0])[i] = 0;
     __syncthreads();
     load_class_tile(job, tx, ty, sh.class_of, sh.tile, t);
     __syncthreads();
+    for (int i = t; i < 288; i += kTile)
+        sh.a.lit_hist[i] = 0;
+    if (t < 2)
+        sh.a.dist_hist[t] = 0;
+    sh.a.n_c[t] = 0;
+    sh.a.w_c[t] = 0;
+    if (t < GCN10_N_RASTERS) {
+        sh.a.s1[t] = 0;
+        sh.a.s2[t] = 0;
+    }
+    RowMasks m;
+    row_masks(sh.tile, t, m);
+    __syncthreads();                                // every mask is built: rows may be rewritten
 
     // pixels and Adler weights per class, run by run along row t (weight of byte i: 65536 - i)
     {
@@ -1376,70 +1470,104 @@ __global__ __launch_bounds__(kTile) void fused_stats_kernel(const FusedJob job)
                 wsum += wgt;
             }
             else {
-                atomicAdd(&sh.n_c[cur], n);
-                atomicAdd(&sh.w_c[cur], wsum);
+                atomicAdd(&sh.a.n_c[cur], n);
+                atomicAdd(&sh.a.w_c[cur], wsum);
                 cur = c;
                 n = 1;
                 wsum = wgt;
             }
         }
-        atomicAdd(&sh.n_c[cur], n);
-        atomicAdd(&sh.w_c[cur], wsum);
+        atomicAdd(&sh.a.n_c[cur], n);
+        atomicAdd(&sh.a.w_c[cur], wsum);
     }
-    RowMasks m;
-    row_masks(sh.tile, t, m);
-    parse_row<kCount>(sh.tile, t, m, sh.lit_hist, sh.dist_hist, nullptr, nullptr);
-    __syncthreads();
-
-    // per raster: literal counts by VALUE, and the Adler-32 of the raster's tile
+    unsigned long long start[4];
+    tokenise_row(sh.tile, t, m, sh.a.lit_hist, sh.a.dist_hist, start);
     {
-        const uint32_t lits = sh.lit_hist[t];       // thread t = class t
-        if (lits)
-            for (uint32_t j = 0; j < job.n_sel; j++)
-                atomicAdd(&sh.H[j][sh.class_val[job.sel[j] * 256 + t]], lits);
-        if ((uint32_t)t < job.n_sel) {
-            const uint8_t *val = sh.class_val + job.sel[t] * 256;
-            unsigned long long s1 = 1, s2 = (unsigned long long)kTileBytes;
-            for (int c = 0; c < 256; c++) {
-                s1 += (unsigned long long)sh.n_c[c] * val[c];
-                s2 += (unsigned long long)sh.w_c[c] * val[c];
-            }
-            sh.adler[t] = (uint32_t)(((s2 % 65521ull) << 16) | (s1 % 65521ull));
-        }
+        unsigned long long *dst = job.tok_start + ((size_t)tix * kTile + t) * 4;
+        dst[0] = start[0];
+        dst[1] = start[1];
+        dst[2] = start[2];
+        dst[3] = start[3];
     }
     __syncthreads();
-    for (uint32_t j = 0; j < job.n_sel; j++) {
-        uint32_t *out = job.t.hist + ((size_t)j * tiles + tix) * kHistWords;
-        for (int i = t; i < kHistWords; i += kTile) {
-            uint32_t v;
-            if (i < 256)
-                v = sh.H[j][i];
-            else if (i == 256)
-                v = 1u;                             // end of block
-            else if (i < 288)
-                v = sh.lit_hist[i];                 // match length symbols: the same for every raster
-            else if (i < 290)
-                v = sh.dist_hist[i - 288];
-            else if (i == 290)
-                v = sh.adler[j];
-            else
-                v = 0u;
-            out[i] = v;
+    // the token tile -> workspace, a wave per row and step
+    {
+        uint32_t *dst = reinterpret_cast<uint32_t *>(job.tok + (size_t)tix * kTileBytes) + (t & 63);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(sh.tile) + (t & 63);
+#pragma unroll 8
+        for (int i = 0; i < kTile / 4; i++) {
+            const int r = i * 4 + (t >> 6);
+            dst[r * (kTile / 4)] = src[r * (kRowStride / 4)];
         }
+    }
+
+    // Adler-32 of every raster's tile: thread t = class t, s1 = 1 + sum n_c val, s2 = N + sum w_c val
+    const uint32_t lits = sh.a.lit_hist[t];
+    {
+        const uint32_t n = sh.a.n_c[t];
+        const uint32_t w = sh.a.w_c[t] % 65521u;
+        for (uint32_t j = 0; j < job.n_sel; j++) {
+            const uint32_t v = class_val[job.sel[j] * 256 + t];
+            const uint32_t p1 = wave_sum64(n * v);              // <= 2^24 in all
+            const uint32_t p2 = wave_sum64(w * v);              // <= 256 * 65520 * 255 < 2^32 in all
+            if ((t & 63) == 0) {
+                atomicAdd(&sh.a.s1[j], p1);
+                atomicAdd(&sh.a.s2[j], p2);
+            }
+        }
+    }
+    // per raster: literal counts by VALUE, kGroup rasters per round
+    for (uint32_t j0 = 0; j0 < job.n_sel; j0 += kGroup) {
+        const uint32_t nj = job.n_sel - j0 < (uint32_t)kGroup ? job.n_sel - j0 : (uint32_t)kGroup;
+        for (uint32_t k = 0; k < nj; k++)
+            sh.a.H[k][t] = 0;
+        __syncthreads();
+        if (lits)
+            for (uint32_t k = 0; k < nj; k++)
+                atomicAdd(&sh.a.H[k][class_val[job.sel[j0 + k] * 256 + t]], lits);
+        __syncthreads();
+        for (uint32_t k = 0; k < nj; k++) {
+            const uint32_t j = j0 + k;
+            uint32_t *out = job.t.hist + ((size_t)j * tiles + tix) * kHistWords;
+            for (int i = t; i < kHistWords; i += kTile) {
+                uint32_t v;
+                if (i < 256)
+                    v = sh.a.H[k][i];
+                else if (i == 256)
+                    v = 1u;                             // end of block
+                else if (i < 288)
+                    v = sh.a.lit_hist[i];               // match length symbols: the same for every raster
+                else if (i < 290)
+                    v = sh.a.dist_hist[i - 288];
+                else if (i == 290)
+                    v = (((65536u % 65521u + sh.a.s2[j] % 65521u) % 65521u) << 16) |
+                        ((1u + sh.a.s1[j]) % 65521u);
+                else
+                    v = 0u;
+                out[i] = v;
+            }
+        }
+        __syncthreads();
     }
 }
 
 template <bool SMALL>
 struct SharedFC {
-    static constexpr int kWords = SMALL ? 12288 / 4 + 16 : kOutWords;
-    uint8_t tile[kTile * kRowStride];
-    uint32_t out[kWords];           // doubles as the staging area of class_of while the tile is built
-    uint8_t lit_len[288];           // per CLASS for indices < 256, then end of block and match symbols
-    uint16_t lit_code[288];
-    uint32_t wave_sum[4];
+    static constexpr int kWords = SMALL ? 8192 / 4 + 16 : kOutWords;
+    uint8_t tile[kTile * kRowStride];   // token tile
+    uint32_t out[kWords];
+    uint32_t lenpack[288][kGroup / 2];  // code lengths of the group's rasters by class / length symbol,
+                                        // two rasters per dword
+    uint32_t cl[288];                   // current raster: code | length << 16
+    uint32_t wave_sum[kGroup][4];
+    uint8_t class_of[SMALL ? 4 : gcn10::kClassCodes * 256];     // stored fallback only
 };
-constexpr int kFusedSmallStream = 12288;
+constexpr int kFusedSmallStream = 8192;
 
+// pass F-C: one workgroup per (tile position, group of kGroup rasters).  The token tile
+// is loaded once; one walk over each row measures it for all rasters of the group (packed
+// 16-bit sums), a prefix sum places the rows, then each raster's stream is a walk that
+// only maps tokens to that raster's codes.
 template <bool SMALL>
 __global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
 {
@@ -1449,30 +1577,134 @@ __global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
     const uint32_t tiles = job.t.across * job.t.down;
     const uint32_t tix = blockIdx.x;
     const uint32_t ty = tix / job.t.across, tx = tix - ty * job.t.across;
+    const uint32_t j0 = blockIdx.y * kGroup;
+    const uint32_t nj = job.n_sel - j0 < (uint32_t)kGroup ? job.n_sel - j0 : (uint32_t)kGroup;
+    const uint8_t *class_val = job.class_of + gcn10::kClassCodes * 256;
 
-    // anything to do for this tile position in this launch?
+    // anything to do for this tile position and group in this launch?
+    int any_stored;
     {
-        int mine = 0;
-        if ((uint32_t)t < job.n_sel) {
-            const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)t * tiles + tix) * kBookBytes);
+        int mine = 0, st = 0;
+        if ((uint32_t)t < nj) {
+            const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)(j0 + t) * tiles + tix) * kBookBytes);
             mine = ((b->stream_bytes <= (uint32_t)kFusedSmallStream) == SMALL) && b->slot != 0xffffffffu;
+            st = mine && b->stream_bytes == (uint32_t)kMaxStream;
         }
         if (!__syncthreads_or(mine))
             return;
+        any_stored = __syncthreads_or(st);
     }
-    static_assert(SharedFC<SMALL>::kWords * 4 >= gcn10::kClassCodes * 256, "class map must fit the output image");
-    uint8_t *class_of_lds = reinterpret_cast<uint8_t *>(sh.out);
-    for (int i = t; i < gcn10::kClassCodes * 256 / 4; i += kTile)
-        reinterpret_cast<uint32_t *>(class_of_lds)[i] = reinterpret_cast<const uint32_t *>(job.class_of)[i];
+    // token tile and this row's match starts
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(job.tok + (size_t)tix * kTileBytes) + (t & 63);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(sh.tile) + (t & 63);
+        uint32_t v[kTile / 4];
+#pragma unroll
+        for (int i = 0; i < kTile / 4; i++)
+            v[i] = src[(i * 4 + (t >> 6)) * (kTile / 4)];
+#pragma unroll
+        for (int i = 0; i < kTile / 4; i++)
+            dst[(i * 4 + (t >> 6)) * (kRowStride / 4)] = v[i];
+    }
+    unsigned long long start[4];
+    {
+        const unsigned long long *src = job.tok_start + ((size_t)tix * kTile + t) * 4;
+        start[0] = src[0];
+        start[1] = src[1];
+        start[2] = src[2];
+        start[3] = src[3];
+    }
+    // code lengths of the group's rasters, by class (a literal of class c is the symbol val(c))
+    uint32_t dist_pack[2][kGroup / 2] = {};
+    for (int i = t; i < 288; i += kTile) {
+#pragma unroll
+        for (int k = 0; k < kGroup; k += 2) {
+            uint32_t pair = 0;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if ((uint32_t)(k + h) < nj) {
+                    const uint32_t j = j0 + k + h;
+                    const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)j * tiles + tix) * kBookBytes);
+                    const uint32_t sym = i < 256 ? class_val[job.sel[j] * 256 + i] : (uint32_t)i;
+                    pair |= (uint32_t)b->lit_len[sym] << (16 * h);
+                }
+            }
+            sh.lenpack[i][k / 2] = pair;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kGroup; k++) {
+        if ((uint32_t)k < nj) {
+            const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)(j0 + k) * tiles + tix) * kBookBytes);
+            dist_pack[0][k / 2] |= (uint32_t)b->dist_len[0] << (16 * (k & 1));
+            dist_pack[1][k / 2] |= ((uint32_t)b->dist_len[1] + 6u) << (16 * (k & 1));
+        }
+    }
+    if (!SMALL && any_stored)
+        for (int i = t; i < gcn10::kClassCodes * 256 / 4; i += kTile)
+            reinterpret_cast<uint32_t *>(sh.class_of)[i] = reinterpret_cast<const uint32_t *>(job.class_of)[i];
     __syncthreads();
-    load_class_tile(job, tx, ty, class_of_lds, sh.tile, t);
-    __syncthreads();
-    RowMasks m;
-    row_masks(sh.tile, t, m);
-    const uint8_t *class_val = job.class_of + gcn10::kClassCodes * 256;
+
+    // bits of row t in every raster of the group
+    uint32_t acc[kGroup / 2] = {};
+    {
+        const uint8_t *row = sh.tile + t * kRowStride;
+        int x = 0;
+        while (x < kTile) {
+            const int p = next_set(start, x);
+            for (; x < p; x++) {
+                const uint32_t *lp = sh.lenpack[row[x]];
+#pragma unroll
+                for (int k = 0; k < kGroup / 2; k++)
+                    acc[k] += lp[k];
+            }
+            if (x >= kTile)
+                break;
+            const uint32_t b0 = row[x], b1 = row[x + 1], b2 = row[x + 2];
+            const uint32_t *lp = sh.lenpack[257u + (b0 & 31u)];
+            const uint32_t far = b0 >> 7;
+            const uint32_t common = (b1 >> 5) * 0x00010001u;
+#pragma unroll
+            for (int k = 0; k < kGroup / 2; k++)
+                acc[k] += lp[k] + common + (far ? dist_pack[1][k] : dist_pack[0][k]);
+            x += (int)b2 + 3;
+        }
+    }
+    // exclusive prefix over rows, all rasters of the group at once
+    uint32_t first_bit[kGroup];
+    {
+        uint32_t v[kGroup];
+        const int lane = t & 63;
+#pragma unroll
+        for (int k = 0; k < kGroup; k++) {
+            const uint32_t mine = (acc[k / 2] >> (16 * (k & 1))) & 0xffffu;
+            uint32_t s = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(s, off, 64);
+                if (lane >= off)
+                    s += up;
+            }
+            if (lane == 63)
+                sh.wave_sum[k][t >> 6] = s;
+            v[k] = s - mine;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kGroup; k++) {
+            uint32_t base = 0;
+            for (int w = 0; w < (t >> 6); w++)
+                base += sh.wave_sum[k][w];
+            first_bit[k] = v[k] + base;
+        }
+    }
     uint8_t *o = reinterpret_cast<uint8_t *>(sh.out);
 
-    for (uint32_t j = 0; j < job.n_sel; j++) {
+#pragma unroll
+    for (int k = 0; k < kGroup; k++) {
+        if ((uint32_t)k >= nj)
+            break;
+        const uint32_t j = j0 + k;
         const Book *book = reinterpret_cast<const Book *>(job.t.books + ((size_t)j * tiles + tix) * kBookBytes);
         const uint32_t stream_bytes = book->stream_bytes;
         const uint32_t slot = book->slot;
@@ -1482,38 +1714,50 @@ __global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
         const uint32_t n_words = (stream_bytes + 3) / 4;
         const uint32_t header_bits = book->header_bits;
         const uint32_t adler = job.t.hist[((size_t)j * tiles + tix) * kHistWords + 290];
-        const uint8_t my_val = class_val[job.sel[j] * 256 + t];     // value of class t in this raster
 
         __syncthreads();                            // the previous raster's image has been copied out
         for (uint32_t i = t; i < n_words + 1; i += kTile)
             sh.out[i] = (i < 64 && !stored) ? book->header[i] : 0u;
-        // code tables by class: a literal of class c is the symbol val(c)
-        sh.lit_len[t] = book->lit_len[my_val];
-        sh.lit_code[t] = book->lit_code[my_val];
-        if (t < 32) {
-            sh.lit_len[256 + t] = book->lit_len[256 + t];
-            sh.lit_code[256 + t] = book->lit_code[256 + t];
+        {
+            const uint32_t v = class_val[job.sel[j] * 256 + t];     // value of class t in this raster
+            sh.cl[t] = (uint32_t)book->lit_code[v] | (uint32_t)book->lit_len[v] << 16;
+            if (t < 32)
+                sh.cl[256 + t] = (uint32_t)book->lit_code[256 + t] | (uint32_t)book->lit_len[256 + t] << 16;
         }
-        CodeView cv;
-        cv.lit_len = sh.lit_len;
-        cv.lit_code = sh.lit_code;
-        cv.dist_len[0] = book->dist_len[0];
-        cv.dist_len[1] = book->dist_len[1];
-        cv.dist_code[0] = book->dist_code[0];
-        cv.dist_code[1] = book->dist_code[1];
+        const uint32_t dcode0 = book->dist_code[0], dlen0 = book->dist_len[0];
+        const uint32_t dcode1 = (uint32_t)book->dist_code[1] | 63u << book->dist_len[1];    // + 6 extra bits: 256 - 193
+        const uint32_t dlen1 = (uint32_t)book->dist_len[1] + 6u;
         __syncthreads();
 
         if (!stored) {
-            const uint32_t bits = parse_row<kMeasure>(sh.tile, t, m, nullptr, nullptr, &cv, nullptr);
-            const uint32_t incl = block_scan(bits, sh.wave_sum, t);
-            RowEmitter em{ sh.out, header_bits + incl - bits, 0ull, 0 };
-            parse_row<kEmit>(sh.tile, t, m, nullptr, nullptr, &cv, &em);
+            RowEmitter em{ sh.out, header_bits + first_bit[k], 0ull, 0 };
+            const uint8_t *row = sh.tile + t * kRowStride;
+            int x = 0;
+            while (x < kTile) {
+                const int p = next_set(start, x);
+                for (; x < p; x++) {
+                    const uint32_t c = sh.cl[row[x]];
+                    em.put(c & 0xffffu, (int)(c >> 16));
+                }
+                if (x >= kTile)
+                    break;
+                const uint32_t b0 = row[x], b1 = row[x + 1], b2 = row[x + 2];
+                const uint32_t c = sh.cl[257u + (b0 & 31u)];
+                const uint32_t l = c >> 16;
+                em.put((c & 0xffffu) | (b1 & 31u) << l, (int)(l + (b1 >> 5)));     // <= 15 + 5 bits
+                if (b0 >> 7)
+                    em.put(dcode1, (int)dlen1);                                     // <= 15 + 6 bits
+                else
+                    em.put(dcode0, (int)dlen0);
+                x += (int)b2 + 3;
+            }
             if (t == kTile - 1)
-                em.put(sh.lit_code[256], sh.lit_len[256]);      // end of block
+                em.put(sh.cl[256] & 0xffffu, (int)(sh.cl[256] >> 16));             // end of block
             em.finish();
         }
         else if (!SMALL) {
-            // stored fallback: the raster's bytes are val(class), two blocks of 32768 bytes
+            // stored fallback: the raster's bytes are val(class), two blocks of 32768 bytes;
+            // the classes are formed again from landcover + soil (the tile in LDS holds tokens)
             if (t == 0) {
                 o[0] = 0x78;
                 o[1] = 0x01;
@@ -1526,11 +1770,17 @@ __global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
                     h[4] = 0x7f;
                 }
             }
-            uint8_t *dst = o + 2 + (t >> 7) * (5 + 32768) + 5 + (t & 127) * kTile;
-            const uint8_t *row = sh.tile + t * kRowStride;
             const uint8_t *val = class_val + job.sel[j] * 256;
-            for (int k = 0; k < kTile; k++)
-                dst[k] = val[row[k]];
+            const uint32_t xc = (uint32_t)(t & 63) * 4u;
+            for (int i = 0; i < kTile / 4; i++) {
+                const int r = i * 4 + (t >> 6);
+                const uint32_t c4 = class_pixels4(job, tx * kTile + xc, ty * kTile + (uint32_t)r, sh.class_of);
+                uint8_t *dst = o + 2 + (r >> 7) * (5 + 32768) + 5 + (r & 127) * kTile + xc;
+                dst[0] = val[c4 & 0xffu];
+                dst[1] = val[(c4 >> 8) & 0xffu];
+                dst[2] = val[(c4 >> 16) & 0xffu];
+                dst[3] = val[c4 >> 24];
+            }
         }
         __syncthreads();
         if (t == 0) {
@@ -1695,7 +1945,9 @@ int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W,
     const uint64_t nblocks = (uint64_t)positions * job.n_sel;
     job.t.n_tiles = (uint32_t)nblocks;
 
-    const size_t need = (size_t)nblocks * ((size_t)kHistWords * 4 + (size_t)kBookBytes);
+    // workspace: statistics + code books per (raster, tile), token tiles + match starts per position
+    const size_t stats_bytes = ((size_t)nblocks * ((size_t)kHistWords * 4 + (size_t)kBookBytes) + 255) & ~(size_t)255;
+    const size_t need = stats_bytes + (size_t)positions * ((size_t)kTileBytes + (size_t)kTile * 32);
     if (need > ctx->deflate_ws_cap) {
         HIP_TRY(hipDeviceSynchronize());
         if (ctx->deflate_ws)
@@ -1707,8 +1959,10 @@ int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W,
     }
     job.t.hist = reinterpret_cast<uint32_t *>(ctx->deflate_ws);
     job.t.books = reinterpret_cast<uint8_t *>(ctx->deflate_ws) + (size_t)nblocks * kHistWords * 4;
+    job.tok = reinterpret_cast<uint8_t *>(ctx->deflate_ws) + stats_bytes;
+    job.tok_start = reinterpret_cast<unsigned long long *>(job.tok + (size_t)positions * kTileBytes);
 
-    static_assert(sizeof(SharedFA) <= 160 * 1024, "fused statistics pass must fit LDS");
+    static_assert(sizeof(SharedFA) <= 80 * 1024, "two fused statistics workgroups per CU");
     static_assert(sizeof(SharedFC<true>) <= 80 * 1024, "two small-stream fused emit workgroups per CU");
     static_assert(sizeof(SharedFC<false>) <= 160 * 1024, "fused emit pass must fit LDS");
     if (!ctx->fused_ready) {
@@ -1733,8 +1987,10 @@ int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W,
     else
         hipLaunchKernelGGL(deflate_codes_kernel, dim3(((uint32_t)nblocks + kBuildThreads - 1) / kBuildThreads),
                            dim3(kBuildThreads), sizeof(Work) * kBuildThreads, s, job.t);
-    hipLaunchKernelGGL(fused_emit_kernel<true>, dim3(positions), dim3(kTile), sizeof(SharedFC<true>), s, job);
-    hipLaunchKernelGGL(fused_emit_kernel<false>, dim3(positions), dim3(kTile), sizeof(SharedFC<false>), s, job);
+    const uint32_t groups = (job.n_sel + kGroup - 1) / kGroup;
+    hipLaunchKernelGGL(fused_emit_kernel<true>, dim3(positions, groups), dim3(kTile), sizeof(SharedFC<true>), s, job);
+    hipLaunchKernelGGL(fused_emit_kernel<false>, dim3(positions, groups), dim3(kTile), sizeof(SharedFC<false>), s,
+                       job);
     HIP_TRY(hipGetLastError());
     return GCN10_OK;
 }
