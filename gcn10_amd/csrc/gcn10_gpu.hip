@@ -837,6 +837,8 @@ void gcn10_gpu_destroy(gcn10_gpu_ctx *ctx)
         (void)hipFree(ctx->d_hx);
     if (ctx->deflate_ws)
         (void)hipFree(ctx->deflate_ws);
+    if (ctx->inflate_ws)
+        (void)hipFree(ctx->inflate_ws);
     if (ctx->d_class_of)
         (void)hipFree(ctx->d_class_of);
     delete ctx;

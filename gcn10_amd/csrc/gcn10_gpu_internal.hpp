@@ -62,6 +62,8 @@ struct gcn10_gpu_ctx {
     bool deflate_ready = false;     // LDS attributes of the tile encoder set on this device
     void *deflate_ws = nullptr;     // per-tile statistics + code books of the tile encoder
     size_t deflate_ws_cap = 0;
+    void *inflate_ws = nullptr;     // linear slots of the tiles being decoded (gcn10_inflate.hip)
+    size_t inflate_ws_cap = 0;
 };
 
 #endif

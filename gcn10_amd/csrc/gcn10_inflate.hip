@@ -1,0 +1,709 @@
+// gcn10_inflate.hip -- zlib/DEFLATE decoding of landcover tiles on the GPU.
+//
+// What it replaces: GDALRasterIO inside load_raster() (/root/reference/src/raster.c:167-176)
+// inflates the ESA WorldCover tiles on the host before the pixel loop sees a byte; the
+// VRT's sources are 36000x36000 DEFLATE GeoTIFFs with 1024x1024 internal tiles
+// (/root/reference/landcover/esa_worldcover_2021.vrt:266-270), 1.3 GB decoded per block.
+// Here the *compressed* tiles cross PCIe (a few % of the raw bytes) and are decoded in
+// HBM: a DEFLATE stream is serial, a block's ~1300 tiles are not, so one wavefront decodes
+// one tile and a launch decodes them all.
+//
+// One wavefront per stream (RFC 1950 wrapper, RFC 1951 stored / fixed / dynamic blocks):
+//   input    each lane holds one dword of a 256-byte piece of the stream (plus the next
+//            piece, already in flight); the bit reader takes dwords with v_readlane at a
+//            wave-uniform index, so the decode state lives in scalar registers
+//   tables   canonical codes are sorted by (length, symbol) with ballots; the 10-bit
+//            (literal/length) and 9-bit (distance) lookup tables are filled entry-parallel,
+//            16 resp. 8 entries per lane; longer codes take a bit-serial canonical walk
+//   window   the last 32 KiB of output live in LDS (reads after writes are ordered there);
+//            a match is copied by all lanes, 64 bytes per step, also when it overlaps itself;
+//            every 16 KiB the finished half goes to HBM as 16 B per lane
+//   output   each tile decodes into its own linear slot; untile_kernel then copies the
+//            wanted window of every tile into the row-major landcover block.
+// Malformed streams end with a status code, never with a wild access or an endless loop
+// (every trip of every loop consumes input bits, and input is bounded).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include "gcn10_gpu.h"
+#include "gcn10_gpu_internal.hpp"
+
+using gcn10::as_stream;
+using gcn10::fail;
+using gcn10::u32x4;
+using gcn10::use_device;
+
+namespace {
+
+constexpr int kWindow = 32768;
+constexpr int kWindowMask = kWindow - 1;
+constexpr int kFlush = 16384;
+constexpr int kLitRoot = 10;
+constexpr int kDistRoot = 9;
+
+enum {
+    kOk = 0,
+    kErrHeader = 1,         // not a zlib stream (CM != 8, FDICT set, bad check bits)
+    kErrBlockType = 2,
+    kErrStored = 3,         // LEN != ~NLEN
+    kErrLengths = 4,        // bad code-length sequence or over-subscribed code
+    kErrCode = 5,           // a bit pattern that is no code of the current block
+    kErrDistance = 6,       // distance reaches before the start of the output
+    kErrInput = 7,          // ran past the end of the compressed bytes
+};
+
+struct Code {               // canonical code, by length
+    uint16_t count[16];
+    uint16_t first[16];     // first code of each length
+    uint16_t offs[16];      // index of its symbol in sorted[]
+};
+
+struct Shared {
+    uint8_t window[kWindow];
+    uint32_t lit_tab[1 << kLitRoot];        // decoded entries (below), 0 = longer code or none
+    uint32_t dist_tab[1 << kDistRoot];
+    uint16_t lit_sorted[288];
+    uint16_t dist_sorted[32];
+    uint8_t lens[320];
+    Code lit, dist;
+};
+
+struct Reader {
+    const uint32_t *in;     // 16-byte aligned start of the stream
+    uint32_t n_dwords;      // dwords that hold stream bytes
+    uint32_t ip;            // next dword to take
+    uint32_t chunk;         // index of the 64-dword piece held in `cur`
+    uint32_t cur, nxt;      // per lane
+    unsigned long long bb;  // bit buffer, LSB first
+    uint32_t bc;            // valid bits in bb
+    int lane;
+};
+
+__device__ __forceinline__ uint32_t load_piece(const Reader &r, uint32_t chunk)
+{
+    const uint32_t i = chunk * 64u + (uint32_t)r.lane;
+    return i < r.n_dwords ? r.in[i] : 0u;
+}
+
+__device__ __forceinline__ void reader_seek(Reader &r, uint32_t dword)
+{
+    r.ip = dword;
+    r.chunk = dword >> 6;
+    r.cur = load_piece(r, r.chunk);
+    r.nxt = load_piece(r, r.chunk + 1);
+    r.bb = 0;
+    r.bc = 0;
+}
+
+__device__ __forceinline__ uint32_t take_dword(Reader &r)
+{
+    const uint32_t c = r.ip >> 6;
+    if (c != r.chunk) {                     // wave-uniform
+        r.cur = r.nxt;
+        r.chunk = c;
+        r.nxt = load_piece(r, c + 1);
+    }
+    const uint32_t v = __builtin_amdgcn_readlane(r.cur, (int)(r.ip & 63u));
+    r.ip++;
+    return v;
+}
+
+// at least 33 bits in the buffer afterwards
+__device__ __forceinline__ void refill(Reader &r)
+{
+    if (r.bc <= 32) {
+        r.bb |= (unsigned long long)take_dword(r) << r.bc;
+        r.bc += 32;
+    }
+}
+
+__device__ __forceinline__ uint32_t take_bits(Reader &r, uint32_t n)
+{
+    const uint32_t v = (uint32_t)r.bb & ((1u << n) - 1u);
+    r.bb >>= n;
+    r.bc -= n;
+    return v;
+}
+
+// bytes of the stream consumed so far (whole bytes only)
+__device__ __forceinline__ uint32_t reader_byte_pos(const Reader &r)
+{
+    return r.ip * 4u - r.bc / 8u;
+}
+
+__device__ __forceinline__ uint32_t uniform(uint32_t v)
+{
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+// Sorts the n symbols of lens[] by (length, symbol) and derives first code / offset per
+// length.  Returns false when the lengths over-subscribe the code space.
+__device__ __forceinline__ bool sort_code(const uint8_t *lens, int n, uint16_t *sorted, Code &c, int lane)
+{
+    uint32_t cnt[16];
+#pragma unroll
+    for (int L = 0; L < 16; L++)
+        cnt[L] = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int s = base + lane;
+        const uint32_t mylen = s < n ? lens[s] : 0u;
+#pragma unroll
+        for (int L = 1; L < 16; L++)
+            cnt[L] += (uint32_t)__builtin_popcountll(__ballot(mylen == (uint32_t)L));
+    }
+    uint32_t offs[16], first[16];
+    int left = 1;
+    bool ok = true;
+    offs[0] = 0;
+    first[0] = 0;
+    offs[1] = 0;
+    first[1] = 0;
+#pragma unroll
+    for (int L = 1; L < 16; L++) {
+        left = left * 2 - (int)cnt[L];
+        if (left < 0)
+            ok = false;
+        if (L < 15) {
+            offs[L + 1] = offs[L] + cnt[L];
+            first[L + 1] = (first[L] + cnt[L]) << 1;
+        }
+    }
+    if (lane < 16) {
+        uint32_t cv = 0, fv = 0, ov = 0;
+#pragma unroll
+        for (int L = 1; L < 16; L++) {
+            if (lane == L) {
+                cv = cnt[L];
+                fv = first[L];
+                ov = offs[L];
+            }
+        }
+        c.count[lane] = (uint16_t)cv;
+        c.first[lane] = (uint16_t)fv;
+        c.offs[lane] = (uint16_t)ov;
+    }
+    uint32_t run[16];
+#pragma unroll
+    for (int L = 0; L < 16; L++)
+        run[L] = offs[L];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int base = 0; base < n; base += 64) {
+        const int s = base + lane;
+        const uint32_t mylen = s < n ? lens[s] : 0u;
+#pragma unroll
+        for (int L = 1; L < 16; L++) {
+            const unsigned long long m = __ballot(mylen == (uint32_t)L);
+            if (mylen == (uint32_t)L)
+                sorted[run[L] + (uint32_t)__builtin_popcountll(m & below)] = (uint16_t)s;
+            run[L] += (uint32_t)__builtin_popcountll(m);
+        }
+    }
+    return ok;
+}
+
+// Table entries, indexed by the low ROOT bits of the bit buffer (codes arrive MSB first, so
+// the buffer's bit 0 is a code's first bit).  Bits 0..3 of an entry = bits to consume, 0 = no
+// code of at most ROOT bits starts here (longer code, or none).
+//   literal/length table   bits 4..5 kind: 0 literals, 1 match length, 2 end of block
+//     literals  bits 6..7 how many (1..3: as many whole literal codes as fit the ROOT bits),
+//               bits 8..31 their bytes, first one lowest
+//     length    bits 6..8 number of extra bits, bits 9..17 base length
+//   distance table         bits 4..7 number of extra bits, bits 8..23 base distance
+//   code-length table      bits 4..8 symbol
+enum { kLiterals = 0, kLength = 1, kEndOfBlock = 2 };
+
+__device__ __forceinline__ uint32_t length_entry(uint32_t sym, uint32_t bits)
+{
+    // sym = 257..285, RFC 1951 3.2.5
+    const uint32_t s = sym - 257u;
+    if (s > 28u)
+        return 0;
+    uint32_t base, eb = 0;
+    if (s < 8u) {
+        base = 3u + s;
+    }
+    else if (s == 28u) {
+        base = 258u;
+    }
+    else {
+        eb = (s - 4u) >> 2;
+        base = 3u + ((4u + (s & 3u)) << eb);
+    }
+    return bits | (uint32_t)kLength << 4 | eb << 6 | base << 9;
+}
+
+__device__ __forceinline__ uint32_t dist_entry(uint32_t sym, uint32_t bits)
+{
+    if (sym > 29u)
+        return 0;
+    uint32_t base, eb = 0;
+    if (sym < 4u) {
+        base = 1u + sym;
+    }
+    else {
+        eb = (sym - 2u) >> 1;
+        base = 1u + ((2u + (sym & 1u)) << eb);
+    }
+    return bits | eb << 4 | base << 8;
+}
+
+// the code at the low bits of `v`, looking at no more than `avail` (<= ROOT) of them:
+// symbol << 4 | length, or 0
+template <int ROOT>
+__device__ __forceinline__ uint32_t walk(uint32_t v, int avail, const uint32_t (&cnt)[ROOT + 1],
+                                         const uint32_t (&first)[ROOT + 1], const uint32_t (&offs)[ROOT + 1],
+                                         const uint16_t *sorted)
+{
+    uint32_t code = 0, e = 0;
+#pragma unroll
+    for (int L = 1; L <= ROOT; L++) {
+        code = (code << 1) | ((v >> (L - 1)) & 1u);
+        const uint32_t d = code - first[L];
+        if (e == 0 && L <= avail && code >= first[L] && d < cnt[L])
+            e = (uint32_t)sorted[offs[L] + d] << 4 | (uint32_t)L;
+    }
+    return e;
+}
+
+enum { kCodeLengthTable = 0, kLitLenTable = 1, kDistTable = 2 };
+
+template <int ROOT, int WHICH>
+__device__ __forceinline__ void fill_table(uint32_t *tab, const uint16_t *sorted, const Code &c, int lane)
+{
+    uint32_t cnt[ROOT + 1], first[ROOT + 1], offs[ROOT + 1];
+#pragma unroll
+    for (int L = 1; L <= ROOT; L++) {
+        cnt[L] = c.count[L];
+        first[L] = c.first[L];
+        offs[L] = c.offs[L];
+    }
+    for (int idx = lane; idx < (1 << ROOT); idx += 64) {
+        const uint32_t w = walk<ROOT>((uint32_t)idx, ROOT, cnt, first, offs, sorted);
+        uint32_t e = 0;
+        if (w != 0) {
+            const uint32_t sym = w >> 4, bits = w & 15u;
+            if (WHICH == kCodeLengthTable) {
+                e = w;
+            }
+            else if (WHICH == kDistTable) {
+                e = dist_entry(sym, bits);
+            }
+            else if (sym == 256u) {
+                e = bits | (uint32_t)kEndOfBlock << 4;
+            }
+            else if (sym > 256u) {
+                e = length_entry(sym, bits);
+            }
+            else {
+                // up to three literals whose codes fit the ROOT bits together
+                uint32_t bytes = sym, n = 1, used = bits;
+#pragma unroll
+                for (int more = 0; more < 2; more++) {
+                    const uint32_t w2 = used < (uint32_t)ROOT && n == (uint32_t)more + 1u
+                                            ? walk<ROOT>((uint32_t)idx >> used, ROOT - (int)used, cnt, first, offs, sorted)
+                                            : 0u;
+                    if (w2 != 0 && (w2 >> 4) < 256u) {
+                        bytes |= (w2 >> 4) << (8 * n);
+                        n++;
+                        used += w2 & 15u;
+                    }
+                }
+                e = used | (uint32_t)kLiterals << 4 | n << 6 | bytes << 8;
+            }
+        }
+        tab[idx] = e;
+    }
+}
+
+// a code longer than the table's root, or none: walk the canonical code bit by bit;
+// symbol << 4 | length, or 0
+__device__ __forceinline__ uint32_t slow_symbol(const Reader &r, const uint16_t *sorted, const Code &c)
+{
+    uint32_t code = 0;
+    for (int L = 1; L < 16; L++) {
+        code = (code << 1) | ((uint32_t)(r.bb >> (L - 1)) & 1u);
+        const uint32_t f = c.first[L], n = c.count[L];
+        if (code >= f && code - f < n)
+            return (uint32_t)sorted[c.offs[L] + code - f] << 4 | (uint32_t)L;
+    }
+    return 0;
+}
+
+struct Output {
+    uint8_t *out;           // this tile's slot in HBM, 16-byte aligned
+    uint32_t limit;         // bytes wanted
+    uint32_t pos;           // bytes produced
+    uint32_t flushed;       // bytes already in HBM (multiple of kFlush)
+};
+
+__device__ __forceinline__ void flush_half(Shared &sh, Output &o, int lane)
+{
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(sh.window + (o.flushed & kWindowMask));
+    u32x4 *dst = reinterpret_cast<u32x4 *>(o.out + o.flushed);
+#pragma unroll 4
+    for (int i = lane; i < kFlush / 16; i += 64)
+        dst[i] = src[i];
+    o.flushed += kFlush;
+}
+
+__device__ __forceinline__ void copy_match(Shared &sh, Output &o, uint32_t len, uint32_t dist, int lane)
+{
+    const uint32_t from = o.pos - dist;
+    if (len <= 64u && dist >= len) {
+        // the usual case: one step, source and destination apart
+        if ((uint32_t)lane < len)
+            sh.window[(o.pos + (uint32_t)lane) & kWindowMask] = sh.window[(from + (uint32_t)lane) & kWindowMask];
+    }
+    else if (dist >= 64u) {
+        // 64 bytes per step; a later step may read what an earlier one wrote (LDS keeps order)
+        for (uint32_t base = 0; base < len; base += 64u) {
+            const uint32_t k = base + (uint32_t)lane;
+            if (k < len)
+                sh.window[(o.pos + k) & kWindowMask] = sh.window[(from + k) & kWindowMask];
+        }
+    }
+    else {
+        // the copy repeats the last `dist` bytes: lane l always writes pattern byte l mod dist
+        // when the step is a multiple of dist
+        uint32_t step = dist;
+        while (step * 2u <= 64u)
+            step *= 2u;
+        const uint32_t q = (uint32_t)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)dist));
+        const uint8_t v = sh.window[(from + ((uint32_t)lane - q * dist)) & kWindowMask];
+        for (uint32_t base = 0; base < len; base += step) {
+            const uint32_t k = base + (uint32_t)lane;
+            if ((uint32_t)lane < step && k < len)
+                sh.window[(o.pos + k) & kWindowMask] = v;
+        }
+    }
+    o.pos += len;
+}
+
+struct TileIn {             // = gcn10_inflate_tile
+    unsigned long long in_off;
+    uint32_t in_len, out_len;
+    uint32_t chunk_w, src_x, src_y, copy_w, copy_h, pad;
+    unsigned long long dst_off;
+};
+static_assert(sizeof(TileIn) == sizeof(gcn10_inflate_tile), "TileIn mirrors the ABI struct");
+
+__global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *comp, const TileIn *tiles, uint32_t n_tiles,
+                                                     uint8_t *scratch, uint32_t slot_bytes, uint32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    Shared &sh = *reinterpret_cast<Shared *>(smem);
+    const int lane = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    if (tile >= n_tiles)
+        return;
+    const TileIn tin = tiles[tile];
+    const uint32_t in_len = tin.in_len;
+
+    Reader r;
+    r.in = reinterpret_cast<const uint32_t *>(comp + tin.in_off);
+    r.n_dwords = (in_len + 3u) / 4u;
+    r.lane = lane;
+    reader_seek(r, 0);
+    Output o;
+    o.out = scratch + (size_t)tile * slot_bytes;
+    o.limit = tin.out_len < slot_bytes ? tin.out_len : slot_bytes;
+    o.pos = 0;
+    o.flushed = 0;
+    uint32_t err = kOk;
+
+    refill(r);
+    {
+        const uint32_t cmf = take_bits(r, 8), flg = take_bits(r, 8);
+        if ((cmf & 15u) != 8u || (cmf >> 4) > 7u || (flg & 0x20u) || ((cmf << 8 | flg) % 31u) != 0u)
+            err = kErrHeader;
+    }
+    bool last = false;
+    while (!err && !last && o.pos < o.limit) {
+        refill(r);
+        last = take_bits(r, 1) != 0;
+        const uint32_t type = take_bits(r, 2);
+        if (type == 0) {
+            // stored: skip to the byte boundary, LEN, NLEN, LEN bytes
+            take_bits(r, r.bc & 7u);
+            refill(r);
+            const uint32_t len = take_bits(r, 16);
+            refill(r);
+            const uint32_t nlen = take_bits(r, 16);
+            if ((len ^ nlen) != 0xffffu) {
+                err = kErrStored;
+                break;
+            }
+            uint32_t at = reader_byte_pos(r);
+            if (at + len > in_len) {
+                err = kErrInput;
+                break;
+            }
+            const uint8_t *src = comp + tin.in_off;
+            uint32_t todo = len;
+            while (todo > 0 && o.pos < o.limit) {
+                uint32_t n = todo < 4096u ? todo : 4096u;
+                if (n > o.limit - o.pos)
+                    n = o.limit - o.pos;
+                for (uint32_t k = lane; k < n; k += 64)
+                    sh.window[(o.pos + k) & kWindowMask] = src[at + k];
+                o.pos += n;
+                at += n;
+                todo -= n;
+                if (o.pos - o.flushed >= (uint32_t)kFlush)
+                    flush_half(sh, o, lane);
+            }
+            at += todo;
+            reader_seek(r, at >> 2);
+            refill(r);
+            take_bits(r, (at & 3u) * 8u);
+            continue;
+        }
+        if (type == 3) {
+            err = kErrBlockType;
+            break;
+        }
+        int n_lit, n_dist;
+        if (type == 1) {
+            // fixed code: lengths 8 / 9 / 7 / 8, 30 distance codes of 5 bits (RFC 1951 3.2.6)
+            for (int i = lane; i < 288; i += 64)
+                sh.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8);
+            if (lane < 32)
+                sh.lens[288 + lane] = 5;
+            n_lit = 288;
+            n_dist = 32;
+        }
+        else {
+            n_lit = (int)take_bits(r, 5) + 257;
+            n_dist = (int)take_bits(r, 5) + 1;
+            const int n_cl = (int)take_bits(r, 4) + 4;
+            if (n_lit > 286 || n_dist > 30) {
+                err = kErrLengths;
+                break;
+            }
+            // code-length code: 19 symbols of up to 7 bits, table over 7 bits in lit_tab
+            if (lane < 19)
+                sh.lens[lane] = 0;
+            for (int i = 0; i < n_cl; i++) {
+                refill(r);
+                const uint32_t v = take_bits(r, 3);
+                // order of RFC 1951 3.2.7
+                // i: 0 1 2 3 | 4 5 6 7 8 9 10 11 12 13 14 15 16 17 18 -> 16 17 18 0 | 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+                const int sym = i < 3 ? 16 + i : i == 3 ? 0 : (i & 1) ? (19 - i) / 2 : 8 + (i - 4) / 2;
+                if (lane == 0)
+                    sh.lens[sym] = (uint8_t)v;
+            }
+            if (!sort_code(sh.lens, 19, sh.lit_sorted, sh.lit, lane)) {
+                err = kErrLengths;
+                break;
+            }
+            fill_table<7, kCodeLengthTable>(sh.lit_tab, sh.lit_sorted, sh.lit, lane);
+            __syncthreads();
+            // the n_lit + n_dist code lengths, run-length coded
+            int have = 0;
+            uint32_t prev = 0;
+            const int total = n_lit + n_dist;
+            while (have < total) {
+                refill(r);
+                const uint32_t e = uniform(sh.lit_tab[(uint32_t)r.bb & 127u]);
+                if (e == 0) {
+                    err = kErrLengths;
+                    break;
+                }
+                take_bits(r, e & 15u);
+                const uint32_t sym = e >> 4;
+                uint32_t rep = 1, val = sym;
+                if (sym == 16) {
+                    if (have == 0) {
+                        err = kErrLengths;
+                        break;
+                    }
+                    rep = 3 + take_bits(r, 2);
+                    val = prev;
+                }
+                else if (sym == 17) {
+                    rep = 3 + take_bits(r, 3);
+                    val = 0;
+                }
+                else if (sym == 18) {
+                    rep = 11 + take_bits(r, 7);
+                    val = 0;
+                }
+                if (have + (int)rep > total) {
+                    err = kErrLengths;
+                    break;
+                }
+                for (uint32_t k = lane; k < rep; k += 64)
+                    sh.lens[have + k] = (uint8_t)val;       // lens[] is re-used: the 19 are in the table now
+                have += (int)rep;
+                prev = val;
+            }
+            if (err)
+                break;
+            // distance lengths follow the literal/length ones: move them to lens[288..]
+            {
+                const uint8_t d = lane < n_dist ? sh.lens[n_lit + lane] : (uint8_t)0;
+                if (lane < 32)
+                    sh.lens[288 + lane] = d;
+                for (int i = n_lit + lane; i < 288; i += 64)
+                    sh.lens[i] = 0;
+            }
+            n_lit = 288;
+            n_dist = 32;
+        }
+        if (!sort_code(sh.lens, n_lit, sh.lit_sorted, sh.lit, lane) ||
+            !sort_code(sh.lens + 288, n_dist, sh.dist_sorted, sh.dist, lane)) {
+            err = kErrLengths;
+            break;
+        }
+        fill_table<kLitRoot, kLitLenTable>(sh.lit_tab, sh.lit_sorted, sh.lit, lane);
+        fill_table<kDistRoot, kDistTable>(sh.dist_tab, sh.dist_sorted, sh.dist, lane);
+        __syncthreads();                        // (one wavefront: orders the table writes before the lookups)
+
+        // the block's symbols.  Every trip produces output or leaves the loop, and output is
+        // bounded, so the loop ends whatever the bits are.
+        uint32_t event = o.flushed + (uint32_t)kFlush < o.limit ? o.flushed + (uint32_t)kFlush : o.limit;
+        // The lookup of the NEXT token is issued before the current token's bytes are written,
+        // so its LDS latency overlaps the copy.
+        refill(r);
+        uint32_t e = uniform(sh.lit_tab[(uint32_t)r.bb & ((1u << kLitRoot) - 1u)]);
+        for (;;) {
+            if (e == 0) {
+                const uint32_t w = uniform(slow_symbol(r, sh.lit_sorted, sh.lit));
+                const uint32_t sym = w >> 4;
+                e = w == 0        ? 0u
+                    : sym < 256u  ? ((w & 15u) | 1u << 6 | sym << 8)
+                    : sym == 256u ? ((w & 15u) | (uint32_t)kEndOfBlock << 4)
+                                  : length_entry(sym, w & 15u);
+                if (e == 0) {
+                    err = kErrCode;
+                    break;
+                }
+            }
+            take_bits(r, e & 15u);
+            const uint32_t kind = (e >> 4) & 3u;
+            if (kind == (uint32_t)kLiterals) {
+                const uint32_t n = (e >> 6) & 3u;
+                const uint32_t lits = e >> 8;
+                refill(r);
+                const uint32_t next = sh.lit_tab[(uint32_t)r.bb & ((1u << kLitRoot) - 1u)];
+                if ((uint32_t)lane < n)
+                    sh.window[(o.pos + (uint32_t)lane) & kWindowMask] = (uint8_t)(lits >> (8 * lane));
+                o.pos += n;
+                e = uniform(next);
+            }
+            else if (kind == (uint32_t)kLength) {
+                uint32_t len = ((e >> 9) & 511u) + take_bits(r, (e >> 6) & 7u);
+                refill(r);
+                uint32_t d = uniform(sh.dist_tab[(uint32_t)r.bb & ((1u << kDistRoot) - 1u)]);
+                if (d == 0) {
+                    const uint32_t w = uniform(slow_symbol(r, sh.dist_sorted, sh.dist));
+                    d = w == 0 ? 0u : dist_entry(w >> 4, w & 15u);
+                    if (d == 0) {
+                        err = kErrCode;
+                        break;
+                    }
+                }
+                take_bits(r, d & 15u);
+                const uint32_t dist = ((d >> 8) & 0xffffu) + take_bits(r, (d >> 4) & 15u);
+                if (dist > o.pos) {
+                    err = kErrDistance;
+                    break;
+                }
+                if (len > o.limit - o.pos)
+                    len = o.limit - o.pos;
+                refill(r);
+                const uint32_t next = sh.lit_tab[(uint32_t)r.bb & ((1u << kLitRoot) - 1u)];
+                copy_match(sh, o, len, dist, lane);
+                e = uniform(next);
+            }
+            else {
+                break;                              // end of block
+            }
+            if (o.pos >= event) {
+                if (o.pos - o.flushed >= (uint32_t)kFlush)
+                    flush_half(sh, o, lane);
+                if (o.pos >= o.limit)
+                    break;
+                event = o.flushed + (uint32_t)kFlush < o.limit ? o.flushed + (uint32_t)kFlush : o.limit;
+            }
+        }
+    }
+    if (!err && reader_byte_pos(r) > in_len + 4u)
+        err = kErrInput;
+
+    // what is still in the window, then zeros up to the tile's size (as a short stream reads on the host)
+    {
+        const uint32_t end = o.pos < o.limit ? o.pos : o.limit;
+        for (uint32_t i = o.flushed + (uint32_t)lane; i < end; i += 64)
+            o.out[i] = sh.window[i & kWindowMask];
+        for (uint32_t i = end + (uint32_t)lane; i < tin.out_len && i < slot_bytes; i += 64)
+            o.out[i] = 0;
+    }
+    if (lane == 0)
+        status[tile] = err;
+}
+
+// The wanted window of every decoded tile -> the row-major landcover block.
+__global__ __launch_bounds__(256) void untile_kernel(const TileIn *tiles, const uint8_t *scratch, uint32_t slot_bytes,
+                                                     uint8_t *dst, unsigned long long dst_stride)
+{
+    typedef uint32_t u32_u __attribute__((aligned(1)));
+    const TileIn tin = tiles[blockIdx.x];
+    const uint8_t *src = scratch + (size_t)blockIdx.x * slot_bytes + (size_t)tin.src_y * tin.chunk_w + tin.src_x;
+    uint8_t *out = dst + tin.dst_off;
+    const uint32_t w4 = tin.copy_w / 4u;
+    for (uint32_t y = blockIdx.y * 4u + (threadIdx.x >> 6); y < tin.copy_h; y += gridDim.y * 4u) {
+        const uint8_t *s = src + (size_t)y * tin.chunk_w;
+        uint8_t *d = out + (size_t)y * dst_stride;
+        for (uint32_t i = threadIdx.x & 63u; i < w4; i += 64u)
+            reinterpret_cast<u32_u *>(d)[i] = reinterpret_cast<const u32_u *>(s)[i];
+        for (uint32_t i = w4 * 4u + (threadIdx.x & 63u); i < tin.copy_w; i += 64u)
+            d[i] = s[i];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gcn10_gpu_inflate_tiles(gcn10_gpu_ctx *ctx, const uint8_t *comp_dev, const gcn10_inflate_tile *tiles_dev,
+                            int n_tiles, uint32_t chunk_bytes, uint8_t *dst_dev, size_t dst_stride,
+                            uint32_t *status_dev, gcn10_stream_t stream)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (n_tiles < 0 || chunk_bytes == 0)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_inflate_tiles: bad shape (%d tiles of %u bytes)", n_tiles, chunk_bytes);
+    if (n_tiles == 0)
+        return GCN10_OK;
+    if (!comp_dev || !tiles_dev || !dst_dev || !status_dev)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_inflate_tiles: null pointer");
+    if ((reinterpret_cast<uintptr_t>(comp_dev) & 15u) != 0)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_inflate_tiles: compressed bytes must be 16-byte aligned");
+    const uint32_t slot = (chunk_bytes + 255u) & ~255u;
+    const size_t need = (size_t)slot * (size_t)n_tiles;
+    if (need > ctx->inflate_ws_cap) {
+        HIP_TRY(hipDeviceSynchronize());        // the old workspace may still be in use
+        if (ctx->inflate_ws)
+            HIP_TRY(hipFree(ctx->inflate_ws));
+        ctx->inflate_ws = nullptr;
+        ctx->inflate_ws_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->inflate_ws, need));
+        ctx->inflate_ws_cap = need;
+    }
+    static_assert(sizeof(Shared) <= 40 * 1024, "four inflate wavefronts per CU");
+    hipStream_t s = as_stream(ctx, stream);
+    uint8_t *scratch = reinterpret_cast<uint8_t *>(ctx->inflate_ws);
+    hipLaunchKernelGGL(inflate_kernel, dim3((uint32_t)n_tiles), dim3(64), sizeof(Shared), s, comp_dev,
+                       reinterpret_cast<const TileIn *>(tiles_dev), (uint32_t)n_tiles, scratch, slot, status_dev);
+    hipLaunchKernelGGL(untile_kernel, dim3((uint32_t)n_tiles, 16), dim3(256), 0, s,
+                       reinterpret_cast<const TileIn *>(tiles_dev), scratch, slot, dst_dev,
+                       (unsigned long long)dst_stride);
+    HIP_TRY(hipGetLastError());
+    return GCN10_OK;
+}
+
+}  // extern "C"

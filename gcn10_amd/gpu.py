@@ -41,7 +41,14 @@ ABI_SYMBOLS = (
     "gcn10_gpu_deflate_arena_bound", "gcn10_gpu_deflate_strip", "gcn10_gpu_time_next_strip",
     "gcn10_gpu_pci_bus_id", "gcn10_gpu_deflate_fused_strip",
     "gcn10_gpu_deflate_fused_available",
+    "gcn10_gpu_inflate_tiles",
 )
+
+
+# struct gcn10_inflate_tile (include/gcn10_gpu.h)
+INFLATE_TILE_DTYPE = np.dtype([("in_off", "<u8"), ("in_len", "<u4"), ("out_len", "<u4"), ("chunk_w", "<u4"),
+                               ("src_x", "<u4"), ("src_y", "<u4"), ("copy_w", "<u4"), ("copy_h", "<u4"),
+                               ("reserved", "<u4"), ("dst_off", "<u8")])
 
 
 class Gcn10GpuError(RuntimeError):
@@ -96,6 +103,7 @@ def lib():
             "gcn10_gpu_pci_bus_id": (i, [i, C.c_char_p, sz]),
             "gcn10_gpu_deflate_fused_strip": (i, [vp, vp, i, i, vp, u, u, vp, sz, vp, vp, vp]),
             "gcn10_gpu_deflate_fused_available": (i, [vp]),
+            "gcn10_gpu_inflate_tiles": (i, [vp, vp, vp, i, u, vp, sz, vp, vp]),
             "gcn10_gpu_deflate_arena_bound": (sz, [i, i, i]),
             "gcn10_gpu_deflate_strip": (i, [vp, vp, i, i, i, vp, sz, vp, vp, vp]),
         }
@@ -341,6 +349,40 @@ class Engine:
             for b in (arena, table, cursor):
                 b.close()
         return data, tab, used
+
+    def inflate_tiles(self, streams: Sequence[bytes], chunk_w: int, chunk_rows: Sequence[int],
+                      windows: Sequence[tuple], dst_shape: tuple, stream=None):
+        """Decodes zlib streams on the GPU (gcn10_gpu_inflate_tiles).
+
+        streams[i] decodes to a chunk of chunk_rows[i] x chunk_w pixels; windows[i] =
+        (src_x, src_y, copy_w, copy_h, dst_x, dst_y) places part of it in a zero-filled uint8
+        raster of dst_shape.  Returns (raster, status uint32[n])."""
+        n = len(streams)
+        H, W = dst_shape
+        tiles = np.zeros(n, dtype=INFLATE_TILE_DTYPE)
+        parts, off = [], 0
+        for k, st in enumerate(streams):
+            sx, sy, cw, ch, dx, dy = windows[k]
+            tiles[k] = (off, len(st), chunk_w * chunk_rows[k], chunk_w, sx, sy, cw, ch, 0, dy * W + dx)
+            pad = (-len(st)) % 16 + 16
+            parts.append(st)
+            parts.append(bytes(pad))
+            off += len(st) + pad
+        comp = np.frombuffer(b"".join(parts) or bytes(16), dtype=np.uint8)
+        bufs = [self.upload(comp, stream), self.upload(tiles.view(np.uint8), stream), self.alloc(max(H * W, 1)),
+                self.alloc(4 * max(n, 1))]
+        try:
+            self.memset(bufs[2].ptr, 0, max(H * W, 1), stream)
+            self.memset(bufs[3].ptr, 0xFF, 4 * max(n, 1), stream)
+            self._chk(lib().gcn10_gpu_inflate_tiles(self._ctx, bufs[0].ptr, bufs[1].ptr, n,
+                                                    max(chunk_w * max(chunk_rows, default=1), 1), bufs[2].ptr, W,
+                                                    bufs[3].ptr, stream), "gcn10_gpu_inflate_tiles")
+            out = self.download(bufs[2].ptr, (H, W), stream=stream)
+            status = self.download(bufs[3].ptr, (n,), dtype=np.uint32, stream=stream)
+        finally:
+            for b in bufs:
+                b.close()
+        return out, status
 
     # -- block level: src/cn.c:205-290 in memory -----------------------------
     def process_block_mem(self, esa: np.ndarray, gt, coarse: np.ndarray, soil_gt,

@@ -200,6 +200,35 @@ int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W,
                                   uint8_t *arena_dev, size_t arena_cap, uint32_t *table_dev,
                                   unsigned long long *cursor_dev, gcn10_stream_t stream);
 
+/* Landcover input decode on the GPU (replaces the inflate GDALRasterIO does on the host inside
+ * load_raster, /root/reference/src/raster.c:167-176).  `tiles_dev` describes n_tiles zlib
+ * streams (TIFF Compression 8 / 32946: one per tile or strip of the landcover files) lying in
+ * `comp_dev`; every stream is decoded by one wavefront into a linear slot of at most
+ * chunk_bytes, and the wanted window of each chunk (copy_w x copy_h pixels from (src_x, src_y)
+ * of a chunk chunk_w pixels wide) is copied to dst_dev + dst_off, rows dst_stride apart.
+ * status_dev[i] = 0, or the reason stream i is not a valid zlib stream (GCN10_INFLATE_E_*); a
+ * stream that ends early leaves zeros, one that is longer than out_len is cut there, as the
+ * host reader (tiff.c) does.  Streams must start at multiples of 16 bytes in comp_dev. */
+typedef struct gcn10_inflate_tile {
+    uint64_t in_off;        /* byte offset of the zlib stream in comp_dev, multiple of 16 */
+    uint32_t in_len;        /* its size in bytes */
+    uint32_t out_len;       /* bytes the chunk decodes to: chunk_w * rows in the chunk */
+    uint32_t chunk_w;       /* pixels per row of the decoded chunk */
+    uint32_t src_x, src_y;  /* first wanted pixel of the chunk */
+    uint32_t copy_w, copy_h;
+    uint32_t reserved;
+    uint64_t dst_off;       /* where pixel (src_x, src_y) goes in dst_dev */
+} gcn10_inflate_tile;
+enum {
+    GCN10_INFLATE_E_HEADER = 1, GCN10_INFLATE_E_BLOCK_TYPE = 2, GCN10_INFLATE_E_STORED = 3,
+    GCN10_INFLATE_E_LENGTHS = 4, GCN10_INFLATE_E_CODE = 5, GCN10_INFLATE_E_DISTANCE = 6,
+    GCN10_INFLATE_E_INPUT = 7
+};
+int gcn10_gpu_inflate_tiles(gcn10_gpu_ctx *ctx, const uint8_t *comp_dev,
+                            const gcn10_inflate_tile *tiles_dev, int n_tiles, uint32_t chunk_bytes,
+                            uint8_t *dst_dev, size_t dst_stride, uint32_t *status_dev,
+                            gcn10_stream_t stream);
+
 /* Launch-shape knobs of the strip kernels, for tuning runs; results never
  * depend on them.  Names: "grid_blocks_per_cu" (1..64), "ilp16" (0 = by raster count | 1 | 2),
  * "ilp1" (1|2|4), "nontemporal" (0|1), "xcd_slabs" (0|1), "prefetch" (-1 = per-kernel default | 0 | 1), "deflate_wave_codes" (0|1: code

@@ -1,0 +1,199 @@
+"""GPU zlib decoding of landcover tiles (include/gcn10_gpu.h, gcn10_gpu_inflate_tiles).
+
+The checker is Python's zlib (stock zlib): every stream it produces -- stored, fixed and
+dynamic blocks, every level / strategy / window size, multi-block streams, matches at the
+32 KiB limit, self-overlapping matches -- must decode on the GPU to the same bytes, through
+the C ABI.  Malformed streams must end with a status, not with a fault.
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+from gcn10_amd import gpu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    with gpu.Engine(0) as e:
+        yield e
+
+
+def _data(kind, n, seed=0):
+    rng = np.random.default_rng(seed)
+    if kind == "zeros":
+        return np.zeros(n, np.uint8)
+    if kind == "noise":
+        return rng.integers(0, 256, n, dtype=np.uint8)
+    if kind == "classes":          # landcover-like: 11 class codes in runs
+        codes = np.array([10, 20, 30, 40, 50, 60, 70, 80, 90, 95, 100], np.uint8)
+        runs = rng.geometric(0.05, size=n // 8 + 16)
+        vals = codes[rng.integers(0, len(codes), len(runs))]
+        return np.repeat(vals, runs)[:n].copy()
+    if kind == "patches":          # 2-D patches, as a 1024-wide tile
+        w = 1024
+        h = (n + w - 1) // w
+        small = rng.integers(0, 11, ((h + 31) // 32, w // 32), dtype=np.uint8) * 10
+        return np.kron(small, np.ones((32, 32), np.uint8))[:h].reshape(-1)[:n].copy()
+    if kind == "skewed":           # long codes: geometric symbol frequencies
+        return np.minimum(rng.geometric(0.35, n), 255).astype(np.uint8)
+    if kind == "period":           # self-overlapping matches of many periods
+        out = []
+        while sum(len(o) for o in out) < n:
+            p = int(rng.integers(1, 70))
+            out.append(np.tile(rng.integers(0, 256, p, dtype=np.uint8), int(rng.integers(2, 40))))
+        return np.concatenate(out)[:n].copy()
+    if kind == "far":              # repeats at the far end of the 32 KiB window
+        blk = rng.integers(0, 256, 32768 - 300, dtype=np.uint8)
+        return np.tile(blk, n // len(blk) + 1)[:n].copy()
+    raise ValueError(kind)
+
+
+def _compress(raw, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=15, flush_every=0):
+    c = zlib.compressobj(level, zlib.DEFLATED, wbits, 9, strategy)
+    if not flush_every:
+        return c.compress(raw.tobytes()) + c.flush()
+    out = []
+    for k in range(0, len(raw), flush_every):
+        out.append(c.compress(raw[k:k + flush_every].tobytes()))
+        out.append(c.flush(zlib.Z_FULL_FLUSH if (k // flush_every) % 2 else zlib.Z_SYNC_FLUSH))
+    out.append(c.flush())
+    return b"".join(out)
+
+
+def _one(engine, stream, n, w=None):
+    w = w or n
+    rows = max(n // w, 1)
+    out, status = engine.inflate_tiles([stream], w, [rows], [(0, 0, w, rows, 0, 0)], (rows, w))
+    return out.reshape(-1), int(status[0])
+
+
+@pytest.mark.parametrize("kind", ["zeros", "noise", "classes", "patches", "skewed", "period", "far"])
+@pytest.mark.parametrize("level", [0, 1, 6, 9])
+def test_levels_and_kinds(engine, kind, level):
+    n = 1024 * 256
+    raw = _data(kind, n, seed=level)
+    got, status = _one(engine, _compress(raw, level), n, 1024)
+    assert status == 0
+    assert np.array_equal(got, raw)
+
+
+@pytest.mark.parametrize("strategy", [zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED])
+@pytest.mark.parametrize("kind", ["classes", "skewed", "noise"])
+def test_strategies(engine, strategy, kind):
+    n = 100000
+    raw = _data(kind, n, seed=3)
+    got, status = _one(engine, _compress(raw, 6, strategy), n)
+    assert status == 0 and np.array_equal(got, raw)
+
+
+@pytest.mark.parametrize("wbits", [9, 10, 12, 15])
+def test_window_sizes(engine, wbits):
+    raw = _data("period", 70000, seed=wbits)
+    got, status = _one(engine, _compress(raw, 9, wbits=wbits), len(raw))
+    assert status == 0 and np.array_equal(got, raw)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 15, 16, 17, 255, 258, 259, 4095, 16384, 16385, 32768, 32769, 65536, 1 << 20])
+def test_sizes(engine, n):
+    raw = _data("classes", n, seed=n)
+    got, status = _one(engine, _compress(raw), n)
+    assert status == 0 and np.array_equal(got, raw)
+
+
+def test_multi_block_streams_with_flushes(engine):
+    raw = np.concatenate([_data("classes", 50000, 1), _data("noise", 70000, 2), _data("zeros", 40000), _data("skewed", 60000, 3)])
+    for every in (1000, 7777, 65536):
+        got, status = _one(engine, _compress(raw, 6, flush_every=every), len(raw))
+        assert status == 0 and np.array_equal(got, raw), every
+    # stored blocks of every alignment: level 0 splits at 65535 bytes
+    got, status = _one(engine, _compress(raw, 0, flush_every=333), len(raw))
+    assert status == 0 and np.array_equal(got, raw)
+
+
+def test_stream_shorter_and_longer_than_the_chunk(engine):
+    raw = _data("classes", 5000, 5)
+    st = _compress(raw)
+    got, status = _one(engine, st, 8192)                 # short stream: zeros follow, as tiff.c does on the host
+    assert status == 0 and np.array_equal(got[:5000], raw) and not got[5000:].any()
+    out, status = engine.inflate_tiles([st], 100, [30], [(0, 0, 100, 30, 0, 0)], (30, 100))
+    assert int(status[0]) == 0 and np.array_equal(out.reshape(-1), raw[:3000])     # long stream: cut
+
+
+def test_many_tiles_with_windows(engine):
+    rng = np.random.default_rng(11)
+    tw, th = 256, 200
+    nx, ny = 9, 7
+    world = np.zeros((ny * th, nx * tw), np.uint8)
+    streams, rows, wins = [], [], []
+    # destination: a window of the world that cuts tiles on every side
+    x0, y0, W, H = 100, 37, nx * tw - 333, ny * th - 111
+    for ty in range(ny):
+        for tx in range(nx):
+            kind = ["classes", "noise", "zeros", "patches", "skewed"][(tx + ty) % 5]
+            t = _data(kind, tw * th, seed=tx * 100 + ty).reshape(th, tw)
+            world[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw] = t
+            lvl = int(rng.integers(0, 10))
+            streams.append(_compress(t.reshape(-1), lvl))
+            rows.append(th)
+            xs, xe = max(x0, tx * tw), min(x0 + W, (tx + 1) * tw)
+            ys, ye = max(y0, ty * th), min(y0 + H, (ty + 1) * th)
+            wins.append((xs - tx * tw, ys - ty * th, xe - xs, ye - ys, xs - x0, ys - y0))
+    out, status = engine.inflate_tiles(streams, tw, rows, wins, (H, W))
+    assert not status.any()
+    assert np.array_equal(out, world[y0:y0 + H, x0:x0 + W])
+
+
+def test_full_size_tiles_of_a_block_row(engine):
+    # 36 tiles of 1024 x 1024, the shape of one tile row of an ESA WorldCover file
+    tiles = [_data(["patches", "classes"][k % 2], 1 << 20, seed=k) for k in range(36)]
+    streams = [_compress(t, 6) for t in tiles]
+    wins = [(0, 0, 1024, 1024, 1024 * k, 0) for k in range(36)]
+    out, status = engine.inflate_tiles(streams, 1024, [1024] * 36, wins, (1024, 36 * 1024))
+    assert not status.any()
+    for k in range(36):
+        assert np.array_equal(out[:, 1024 * k:1024 * (k + 1)].reshape(-1), tiles[k]), k
+
+
+def _zlib_result(stream, n):
+    d = zlib.decompressobj()
+    try:
+        return d.decompress(stream, n)
+    except zlib.error:
+        return None
+
+
+def test_malformed_streams_report_a_status(engine):
+    rng = np.random.default_rng(5)
+    raw = _data("classes", 60000, 9)
+    good = _compress(raw, 6)
+    cases = [b"", b"\x78", b"\x78\x9c", b"\x00" * 64, b"\xff" * 64, b"\x78\x9c\x07" + b"\x00" * 10,
+             good[: len(good) // 2], good[:10], b"\x78\x9c\x01\x05\x00\xfa\xfe" + b"abcde",      # bad NLEN
+             bytes([0x78, 0x9C]) + bytes(rng.integers(0, 256, 500, dtype=np.uint8))]
+    for k in range(40):                             # single-byte corruptions of a good stream
+        b = bytearray(good)
+        b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        cases.append(bytes(b))
+    out_rows = len(raw) // 100
+    streams = cases
+    wins = [(0, 0, 100, out_rows, 0, k * out_rows) for k in range(len(streams))]
+    out, status = engine.inflate_tiles(streams, 100, [out_rows] * len(streams), wins, (out_rows * len(streams), 100))
+    assert status[:9].all(), status[:9]              # the hand-made ones are all invalid
+    for k, st in enumerate(streams):
+        if status[k] == 0:                          # accepted: then it decodes as zlib decodes it
+            ref = _zlib_result(st, len(raw))
+            got = out[k * out_rows:(k + 1) * out_rows].reshape(-1)
+            if ref is not None:
+                assert bytes(got[:len(ref)]) == ref, k
+    # a distance that reaches before the start of the data
+    # fixed block whose first symbol is a match (length 3, distance 1): nothing to copy from
+    _, st = _one(engine, bytes([0x78, 0x9C, 0x03, 0x02, 0, 0, 0, 0]), 100)
+    assert st == 6
+
+
+def test_argument_errors(engine):
+    with pytest.raises(gpu.Gcn10GpuError):
+        engine._chk(gpu.lib().gcn10_gpu_inflate_tiles(engine._ctx, None, None, 3, 100, None, 100, None, None), "x")
+    assert gpu.lib().gcn10_gpu_inflate_tiles(engine._ctx, None, None, 0, 100, None, 100, None, None) == 0
