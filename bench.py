@@ -60,6 +60,21 @@ def synth_block(seed: int, size: int, pattern: str):
         n = (size + 63) // 64
         small = lut[rng.integers(0, 256, size=(n, n), dtype=np.uint8)]
         esa = np.ascontiguousarray(np.repeat(np.repeat(small, 64, axis=0), 64, axis=1)[:size, :size])
+    elif pattern == "natural":
+        # between the extremes (tools/ only, not a bench.py workload): half the 256-px cells are
+        # 64-px patches, half 8-px blobs, 3 % of all pixels flipped; one 4096^2 piece repeated
+        p = min(size, 4096)
+        n = (p + 63) // 64
+        coarse_p = np.repeat(np.repeat(lut[rng.integers(0, 256, size=(n, n), dtype=np.uint8)], 64, axis=0), 64, axis=1)[:p, :p]
+        m = (p + 7) // 8
+        fine_p = np.repeat(np.repeat(lut[rng.integers(0, 256, size=(m, m), dtype=np.uint8)], 8, axis=0), 8, axis=1)[:p, :p]
+        k = (p + 255) // 256
+        pick = np.repeat(np.repeat(rng.random((k, k)) < 0.5, 256, axis=0), 256, axis=1)[:p, :p]
+        piece = np.where(pick, coarse_p, fine_p)
+        flip = rng.random((p, p)) < 0.03
+        piece = np.where(flip, lut[rng.integers(0, 256, size=(p, p), dtype=np.uint8)], piece).astype(np.uint8)
+        reps = (size + p - 1) // p
+        esa = np.ascontiguousarray(np.tile(piece, (reps, reps))[:size, :size])
     else:
         # i.i.d. pixels; one random slab repeated down the block (the content repeats at
         # different addresses, so no cache can profit) keeps host-side generation short

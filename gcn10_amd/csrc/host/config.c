@@ -45,6 +45,7 @@ int gcn10_config_parse(const char *path, gcn10_config *cfg, char *err, size_t er
 
     memset(cfg, 0, sizeof *cfg);
     cfg->gpu_deflate = 2;
+    cfg->gpu_inflate = 1;
     f = fopen(path, "r");
     if (!f) {
         snprintf(err, errcap, "cannot open config '%s'", path);     /* src/config.c:52 */
@@ -82,6 +83,8 @@ int gcn10_config_parse(const char *path, gcn10_config *cfg, char *err, size_t er
             cfg->workers_per_gpu = atoi(val);
         else if (!strcmp(key, "strip_rows"))
             cfg->strip_rows = atoi(val);
+        else if (!strcmp(key, "gpu_inflate"))
+            cfg->gpu_inflate = atoi(val) != 0;
         else if (!strcmp(key, "io_threads"))
             cfg->io_threads = atoi(val);
         else if (!strcmp(key, "deflate_level"))

@@ -69,7 +69,7 @@ static void load_once(void)
     BIND(event_record); BIND(event_sync); BIND(stream_wait_event); BIND(event_elapsed_ms);
     BIND(set_tables); BIND(prepare_tile); BIND(cn_strip);
     BIND(deflate_arena_bound); BIND(deflate_strip); BIND(pci_bus_id);
-    BIND(deflate_fused_strip); BIND(deflate_fused_available);
+    BIND(deflate_fused_strip); BIND(deflate_fused_available); BIND(inflate_tiles);
 #undef BIND
     if (g_api.abi_version() != GCN10_GPU_ABI_VERSION) {
         snprintf(g_err, sizeof g_err, "%s has ABI version %d, expected %d", g_path,

@@ -29,6 +29,33 @@ int gcn10_tiff_read_window_mt(struct gcn10_tiff *t, int xoff, int yoff, int xcou
 int gcn10_raster_read_mt(gcn10_raster *r, int xoff, int yoff, int xcount, int ycount, uint8_t *dst,
                          gcn10_pool *pool, char *err, size_t errcap);
 
+/* Read plans: the compressed chunks (tiles or strips) of a window, for decoding on the GPU
+ * (gcn10_gpu_inflate_tiles) instead of on the I/O pool. */
+struct gcn10_chunk_ref {
+    int fd;                     /* file that holds the chunk (stays open while the plan lives) */
+    uint64_t file_off;
+    uint32_t nbytes;            /* compressed size */
+    uint32_t chunk_w, rows;     /* decoded shape */
+    uint32_t src_x, src_y;      /* first wanted pixel of the chunk */
+    uint32_t copy_w, copy_h;
+    uint32_t dst_x, dst_y;      /* where it goes in the window */
+};
+struct gcn10_read_plan {
+    struct gcn10_chunk_ref *chunks;
+    size_t n, cap;
+    struct gcn10_tiff **opened; /* VRT sources opened for this plan */
+    int n_opened;
+    uint64_t covered;           /* pixels of the window the chunks fill; the rest reads as 0 */
+    uint32_t max_chunk_bytes;   /* largest decoded chunk */
+};
+/* 0 = planned; 1 = this window cannot be decoded on the GPU (other compression, predictor,
+ * overlapping mosaic sources ...): use gcn10_raster_read_mt; -1 = error (err is set). */
+int gcn10_raster_plan_window(gcn10_raster *r, int xoff, int yoff, int xcount, int ycount,
+                             struct gcn10_read_plan *plan, char *err, size_t errcap);
+int gcn10_tiff_plan_window(struct gcn10_tiff *t, int xoff, int yoff, int xcount, int ycount, int dst_x,
+                           int dst_y, struct gcn10_read_plan *plan, char *err, size_t errcap);
+void gcn10_read_plan_free(struct gcn10_read_plan *plan);
+
 /* gpuapi.c: include/gcn10_gpu.h bound with dlopen */
 struct gcn10_gpu_api {
     bool loaded;
@@ -61,6 +88,8 @@ struct gcn10_gpu_api {
     int (*cn_strip)(gcn10_gpu_ctx *, const uint8_t *, int, int, const int32_t *, unsigned, unsigned,
                     uint8_t *const[GCN10_N_RASTERS], gcn10_stream_t);
     int (*pci_bus_id)(int, char *, size_t);
+    int (*inflate_tiles)(gcn10_gpu_ctx *, const uint8_t *, const gcn10_inflate_tile *, int, uint32_t, uint8_t *,
+                         size_t, uint32_t *, gcn10_stream_t);
     int (*deflate_fused_available)(gcn10_gpu_ctx *);
     int (*deflate_fused_strip)(gcn10_gpu_ctx *, const uint8_t *, int, int, const int32_t *, unsigned, unsigned,
                                uint8_t *, size_t, uint32_t *, unsigned long long *, gcn10_stream_t);

@@ -81,6 +81,16 @@ struct worker {
     size_t ci_cap, cj_cap;
     atomic_bool failed;                     /* a sink job of the current block failed */
     bool fused;                             /* this worker's tables allow the fused encoder */
+    /* landcover decoded on the GPU (gpu_inflate): the block's compressed chunks and where they go */
+    uint8_t *h_comp, *d_comp;               /* h_comp pinned */
+    size_t h_comp_cap, d_comp_cap;
+    gcn10_inflate_tile *h_jobs, *d_jobs;    /* h_jobs pinned */
+    uint32_t *h_status, *d_status;          /* h_status pinned */
+    size_t jobs_cap;
+    uint8_t *d_block;                       /* the decoded landcover block, W x H */
+    size_t block_cap;
+    gcn10_event_t ev_comp, ev_inflate;
+    size_t n_inflate;                       /* chunks of the block in flight */
     int blocks_done;
     double busy_seconds;
     double t_read, t_gpu_wait, t_sink_wait, t_setup;   /* where the worker thread's time goes */
@@ -104,6 +114,7 @@ struct run {
     bool null_sink;                         /* GCN10_SINK=null: no compression, no files */
     bool gpu_deflate;                       /* tiles are encoded on the GPU */
     bool fused;                             /* ... straight from landcover + soil (no CN rasters in HBM) */
+    bool gpu_inflate;                       /* DEFLATE landcover tiles are decoded on the GPU */
     int n_devices;                          /* visible GPUs; worker i uses device i % n_devices */
     int outer_rank, outer_size;             /* this process among the processes of an mpirun / srun */
 };
@@ -443,6 +454,190 @@ static void output_path(char *out, size_t cap, const char *cond, const char *hc,
     }
 }
 
+/* compressed chunks of a read plan -> pinned staging, a slice per pool job */
+struct comp_job {
+    const struct gcn10_chunk_ref *chunks;
+    const gcn10_inflate_tile *jobs;
+    size_t n;
+    uint8_t *dst;
+    pthread_mutex_t *mu;
+    pthread_cond_t *cv;
+    int *pending, *failed;
+};
+
+static void comp_job_run(void *arg)
+{
+    struct comp_job *j = arg;
+    int bad = 0;
+
+    for (size_t i = 0; i < j->n && !bad; i++) {
+        uint8_t *p = j->dst + j->jobs[i].in_off;
+        size_t left = j->chunks[i].nbytes;
+        uint64_t off = j->chunks[i].file_off;
+
+        while (left > 0) {
+            ssize_t got = pread(j->chunks[i].fd, p, left, (off_t)off);
+
+            if (got <= 0) {
+                bad = 1;
+                break;
+            }
+            p += got;
+            off += (uint64_t)got;
+            left -= (size_t)got;
+        }
+        memset(p, 0, 16);               /* the decoder's bit reader may look a few bytes ahead */
+    }
+    pthread_mutex_lock(j->mu);
+    if (bad)
+        *j->failed = 1;
+    if (--*j->pending == 0)
+        pthread_cond_broadcast(j->cv);
+    pthread_mutex_unlock(j->mu);
+    free(j);
+}
+
+/* Landcover window of the block -> w->d_block through the GPU decoder.  0 = issued on
+ * s_kernel (statuses arrive with ev_inflate), 1 = this window needs the host reader,
+ * -1 = error (logged). */
+static int inflate_block(struct worker *w, int xoff, int yoff, int W, int H, int block_id)
+{
+    struct run *r = w->run;
+    const struct gcn10_gpu_api *g = r->gpu;
+    struct gcn10_read_plan plan;
+    char err[1024] = "";
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    pthread_cond_t cv = PTHREAD_COND_INITIALIZER;
+    int pending = 0, failed = 0, rc;
+    size_t comp_bytes = 0;
+    double t0 = now_seconds();
+
+    rc = gcn10_raster_plan_window(w->esa, xoff, yoff, W, H, &plan, err, sizeof err);
+    if (rc > 0)
+        return 1;
+    if (rc < 0) {
+        wlog(w, "ERROR", true, "%s", err);
+        wlog(w, "ERROR", true, "esa load failed for block %d", block_id);
+        return -1;
+    }
+    rc = -1;
+    if (plan.n > w->jobs_cap) {
+        if (w->h_jobs) g->host_free(w->ctx, w->h_jobs);
+        if (w->d_jobs) g->free(w->ctx, w->d_jobs);
+        if (w->h_status) g->host_free(w->ctx, w->h_status);
+        if (w->d_status) g->free(w->ctx, w->d_status);
+        w->h_jobs = NULL;
+        w->d_jobs = NULL;
+        w->h_status = NULL;
+        w->d_status = NULL;
+        w->jobs_cap = 0;
+        if (g->host_alloc(w->ctx, plan.n * sizeof *w->h_jobs, (void **)&w->h_jobs) != 0 ||
+            g->malloc(w->ctx, plan.n * sizeof *w->d_jobs, (void **)&w->d_jobs) != 0 ||
+            g->host_alloc(w->ctx, plan.n * 4, (void **)&w->h_status) != 0 ||
+            g->malloc(w->ctx, plan.n * 4, (void **)&w->d_status) != 0)
+            goto gpu_fail;
+        w->jobs_cap = plan.n;
+    }
+    for (size_t i = 0; i < plan.n; i++) {
+        const struct gcn10_chunk_ref *c = &plan.chunks[i];
+        gcn10_inflate_tile *j = &w->h_jobs[i];
+
+        j->in_off = comp_bytes;
+        j->in_len = c->nbytes;
+        j->out_len = c->chunk_w * c->rows;
+        j->chunk_w = c->chunk_w;
+        j->src_x = c->src_x;
+        j->src_y = c->src_y;
+        j->copy_w = c->copy_w;
+        j->copy_h = c->copy_h;
+        j->reserved = 0;
+        j->dst_off = (uint64_t)c->dst_y * (uint64_t)W + c->dst_x;
+        comp_bytes += (((size_t)c->nbytes + 15) & ~(size_t)15) + 16;
+        w->h_status[i] = 0xffffffffu;
+    }
+    if (comp_bytes > w->h_comp_cap) {
+        size_t cap = comp_bytes + comp_bytes / 4 + 4096;
+
+        if (w->h_comp) g->host_free(w->ctx, w->h_comp);
+        if (w->d_comp) g->free(w->ctx, w->d_comp);
+        w->h_comp = NULL;
+        w->d_comp = NULL;
+        w->h_comp_cap = w->d_comp_cap = 0;
+        if (g->host_alloc(w->ctx, cap, (void **)&w->h_comp) != 0 ||
+            g->malloc(w->ctx, cap, (void **)&w->d_comp) != 0)
+            goto gpu_fail;
+        w->h_comp_cap = w->d_comp_cap = cap;
+    }
+    if (ensure_dev(w, (void **)&w->d_block, &w->block_cap, (size_t)W * (size_t)H) != 0)
+        goto out;
+    /* compressed bytes: a few dozen chunks per pool job */
+    for (size_t i = 0; i < plan.n; i += 32) {
+        struct comp_job *j = malloc(sizeof *j);
+        struct comp_job job = { plan.chunks + i, w->h_jobs + i, plan.n - i < 32 ? plan.n - i : 32, w->h_comp,
+                                &mu, &cv, &pending, &failed };
+
+        if (!j || !r->pool) {
+            struct comp_job *tmp = j ? j : malloc(sizeof *tmp);
+
+            if (!tmp) {
+                failed = 1;
+                break;
+            }
+            *tmp = job;
+            pthread_mutex_lock(&mu);
+            pending++;
+            pthread_mutex_unlock(&mu);
+            comp_job_run(tmp);
+            continue;
+        }
+        *j = job;
+        pthread_mutex_lock(&mu);
+        pending++;
+        pthread_mutex_unlock(&mu);
+        gcn10_pool_submit(r->pool, comp_job_run, j);
+    }
+    pthread_mutex_lock(&mu);
+    while (pending > 0)
+        pthread_cond_wait(&cv, &mu);
+    pthread_mutex_unlock(&mu);
+    w->t_read += now_seconds() - t0;
+    if (failed) {
+        wlog(w, "ERROR", true, "gdalrasterio error: cannot read the landcover tiles of the window %d,%d %dx%d",
+             xoff, yoff, W, H);
+        wlog(w, "ERROR", true, "esa load failed for block %d", block_id);
+        goto out;
+    }
+    if (plan.n == 0) {
+        if (g->memset(w->ctx, w->d_block, 0, (size_t)W * (size_t)H, w->s_kernel) != 0 ||
+            g->event_record(w->ctx, w->ev_inflate, w->s_kernel) != 0)
+            goto gpu_fail;
+        rc = 0;
+        goto out;
+    }
+    if (g->memcpy_h2d(w->ctx, w->d_comp, w->h_comp, comp_bytes, w->s_h2d) != 0 ||
+        g->memcpy_h2d(w->ctx, w->d_jobs, w->h_jobs, plan.n * sizeof *w->h_jobs, w->s_h2d) != 0 ||
+        g->memcpy_h2d(w->ctx, w->d_status, w->h_status, plan.n * 4, w->s_h2d) != 0 ||
+        g->event_record(w->ctx, w->ev_comp, w->s_h2d) != 0 ||
+        g->stream_wait_event(w->ctx, w->s_kernel, w->ev_comp) != 0 ||
+        (plan.covered < (uint64_t)W * (uint64_t)H &&
+         g->memset(w->ctx, w->d_block, 0, (size_t)W * (size_t)H, w->s_kernel) != 0) ||
+        g->inflate_tiles(w->ctx, w->d_comp, w->d_jobs, (int)plan.n, plan.max_chunk_bytes, w->d_block,
+                         (size_t)W, w->d_status, w->s_kernel) != 0 ||
+        g->memcpy_d2h(w->ctx, w->h_status, w->d_status, plan.n * 4, w->s_kernel) != 0 ||
+        g->event_record(w->ctx, w->ev_inflate, w->s_kernel) != 0)
+        goto gpu_fail;
+    w->n_inflate = plan.n;
+    rc = 0;
+    goto out;
+
+gpu_fail:
+    wlog(w, "ERROR", true, "gpu: %s", g->last_error());
+out:
+    /* the files may close: the compressed bytes are in pinned memory now */
+    gcn10_read_plan_free(&plan);
+    return rc;
+}
+
 /* returns 0 (done or skipped like the reference skips) or -1 for errors the
  * reference answers with MPI_Abort */
 static int process_block(struct worker *w, int block_id)
@@ -457,7 +652,7 @@ static int process_block(struct worker *w, int block_id)
     int32_t *ci = NULL, *cj = NULL;
     gcn10_tiff_writer *tifs[GCN10_N_RASTERS] = { 0 };
     int rc = 0, bi, n_strips;
-    bool ok = false;
+    bool ok = false, inflated = false;
 
     /* block geometry: attribute filter "ID"=<id>, first feature (src/cn.c:162-184) */
     bi = gcn10_blocks_find(&r->blocks, block_id);
@@ -543,6 +738,17 @@ static int process_block(struct worker *w, int block_id)
         goto out;
     }
 
+    /* DEFLATE landcover (the ESA tiles): compressed chunks -> HBM -> decoded there */
+    w->n_inflate = 0;
+    if (r->gpu_inflate) {
+        int irc = inflate_block(w, xoff, yoff, W, H, block_id);
+
+        if (irc < 0) {
+            goto out;               /* logged; the block is skipped as after a failed load_raster */
+        }
+        inflated = irc == 0;
+    }
+
     /* strips: rows are multiples of 256 (whole GeoTIFF tile rows) and of 16
      * (16-byte aligned strip starts for any W) */
     n_strips = (H + r->strip_rows - 1) / r->strip_rows;
@@ -561,30 +767,34 @@ static int process_block(struct worker *w, int block_id)
         }
         wait_sink(b);
 
-        /* landcover rows straight into the pinned strip (replaces the malloc +
-         * GDALRasterIO of src/raster.c:169-178) */
-        double t_r0 = now_seconds();
-        /* the strip's landcover tiles are decoded concurrently on the I/O pool */
-        int read_rc = gcn10_raster_read_mt(w->esa, xoff, yoff + y0, W, rows, b->h_esa, r->pool, err,
-                                           sizeof err);
+        const uint8_t *d_esa = inflated ? w->d_block + (size_t)y0 * (size_t)W : b->d_esa;
 
-        w->t_read += now_seconds() - t_r0;
-        if (read_rc != 0) {
-            wlog(w, "ERROR", true, "%s", err);
-            wlog(w, "ERROR", true, "esa load failed for block %d", block_id);
-            goto out;
+        if (!inflated) {
+            /* landcover rows straight into the pinned strip (replaces the malloc +
+             * GDALRasterIO of src/raster.c:169-178) */
+            double t_r0 = now_seconds();
+            /* the strip's landcover tiles are decoded concurrently on the I/O pool */
+            int read_rc = gcn10_raster_read_mt(w->esa, xoff, yoff + y0, W, rows, b->h_esa, r->pool, err,
+                                               sizeof err);
+
+            w->t_read += now_seconds() - t_r0;
+            if (read_rc != 0) {
+                wlog(w, "ERROR", true, "%s", err);
+                wlog(w, "ERROR", true, "esa load failed for block %d", block_id);
+                goto out;
+            }
+            if (g->memcpy_h2d(w->ctx, b->d_esa, b->h_esa, px, w->s_h2d) != 0 ||
+                g->event_record(w->ctx, b->ev_h2d, w->s_h2d) != 0 ||
+                g->stream_wait_event(w->ctx, w->s_kernel, b->ev_h2d) != 0)
+                goto gpu_fail;
         }
-        if (g->memcpy_h2d(w->ctx, b->d_esa, b->h_esa, px, w->s_h2d) != 0 ||
-            g->event_record(w->ctx, b->ev_h2d, w->s_h2d) != 0 ||
-            g->stream_wait_event(w->ctx, w->s_kernel, b->ev_h2d) != 0)
-            goto gpu_fail;
         for (int k = 0; k < GCN10_N_RASTERS; k++)
             outs[k] = b->d_out[k];
         if (w->fused) {
             /* landcover + soil -> 18 x compressed tiles in one device pass, no CN strip in HBM */
             int across = (W + TILE - 1) / TILE, down = (rows + TILE - 1) / TILE;
 
-            if (g->deflate_fused_strip(w->ctx, b->d_esa, W, rows, w->d_cj + y0,
+            if (g->deflate_fused_strip(w->ctx, d_esa, W, rows, w->d_cj + y0,
                                        GCN10_COND_DRAINED | GCN10_COND_UNDRAINED, 0x1ffu, b->d_arena,
                                        b->arena_cap, b->d_table, b->d_cursor, w->s_kernel) != 0 ||
                 g->event_record(w->ctx, b->ev_kernel, w->s_kernel) != 0 ||
@@ -595,7 +805,7 @@ static int process_block(struct worker *w, int block_id)
                 g->event_record(w->ctx, b->ev_meta, w->s_d2h) != 0)
                 goto gpu_fail;
         }
-        else if (g->cn_strip(w->ctx, b->d_esa, W, rows, w->d_cj + y0,
+        else if (g->cn_strip(w->ctx, d_esa, W, rows, w->d_cj + y0,
                              GCN10_COND_DRAINED | GCN10_COND_UNDRAINED, 0x1ffu, outs, w->s_kernel) != 0 ||
                  g->event_record(w->ctx, b->ev_kernel, w->s_kernel) != 0 ||
                  g->stream_wait_event(w->ctx, w->s_d2h, b->ev_kernel) != 0)
@@ -643,6 +853,19 @@ static int process_block(struct worker *w, int block_id)
     for (int i = 0; i < NBUF; i++)
         wait_sink(&w->buf[i]);
     ok = !atomic_load(&w->failed);
+    if (inflated && w->n_inflate > 0) {
+        /* every landcover stream must have been a valid one */
+        if (g->event_sync(w->ctx, w->ev_inflate) != 0)
+            goto gpu_fail;
+        for (size_t i = 0; i < w->n_inflate; i++)
+            if (w->h_status[i] != 0) {
+                wlog(w, "ERROR", true, "gdalrasterio error: cannot decode a tile of the window %d,%d %dx%d "
+                                       "(stream %zu, reason %u)", xoff, yoff, W, H, i, w->h_status[i]);
+                wlog(w, "ERROR", true, "esa load failed for block %d", block_id);
+                ok = false;
+                break;
+            }
+    }
     goto out;
 
 gpu_fail:
@@ -712,6 +935,15 @@ static void worker_teardown(struct worker *w)
             if (b->ev_d2h) g->event_destroy(w->ctx, b->ev_d2h);
             if (b->ev_meta) g->event_destroy(w->ctx, b->ev_meta);
         }
+        if (w->ev_comp) g->event_destroy(w->ctx, w->ev_comp);
+        if (w->ev_inflate) g->event_destroy(w->ctx, w->ev_inflate);
+        if (w->h_comp) g->host_free(w->ctx, w->h_comp);
+        if (w->d_comp) g->free(w->ctx, w->d_comp);
+        if (w->h_jobs) g->host_free(w->ctx, w->h_jobs);
+        if (w->d_jobs) g->free(w->ctx, w->d_jobs);
+        if (w->h_status) g->host_free(w->ctx, w->h_status);
+        if (w->d_status) g->free(w->ctx, w->d_status);
+        if (w->d_block) g->free(w->ctx, w->d_block);
         if (w->d_coarse) g->free(w->ctx, w->d_coarse);
         if (w->d_ci) g->free(w->ctx, w->d_ci);
         if (w->d_cj) g->free(w->ctx, w->d_cj);
@@ -810,6 +1042,8 @@ static int worker_setup(struct worker *w)
     GPU_TRY(w, g->stream_create(w->ctx, &w->s_h2d));
     GPU_TRY(w, g->stream_create(w->ctx, &w->s_kernel));
     GPU_TRY(w, g->stream_create(w->ctx, &w->s_d2h));
+    GPU_TRY(w, g->event_create(w->ctx, &w->ev_comp));
+    GPU_TRY(w, g->event_create(w->ctx, &w->ev_inflate));
     for (int i = 0; i < NBUF; i++) {
         GPU_TRY(w, g->event_create(w->ctx, &w->buf[i].ev_h2d));
         GPU_TRY(w, g->event_create(w->ctx, &w->buf[i].ev_kernel));
@@ -933,6 +1167,7 @@ int gcn10_run(const gcn10_run_options *opt)
     r->deflate_level = r->cfg.deflate_level;
     r->gpu_deflate = r->cfg.gpu_deflate != 0;
     r->fused = r->cfg.gpu_deflate == 2;
+    r->gpu_inflate = r->cfg.gpu_inflate != 0;
 
     /* GPUs: one worker ("rank") each */
     r->gpu = gcn10_gpu_api_get(err, sizeof err);
@@ -1113,11 +1348,11 @@ int gcn10_run(const gcn10_run_options *opt)
             gw += r->workers[i].t_gpu_wait;
             sw += r->workers[i].t_sink_wait;
         }
-        snprintf(msg, sizeof msg, "timing: %d blocks, %.3f s wall, %d gpu worker(s)%s%s; worker seconds: "
+        snprintf(msg, sizeof msg, "timing: %d blocks, %.3f s wall, %d gpu worker(s)%s%s%s; worker seconds: "
                  "in blocks %.3f, reading landcover %.3f, waiting for gpu %.3f, waiting for sink %.3f",
                  done_blocks, now_seconds() - t_start, r->n_workers, r->null_sink ? ", null sink" : "",
-                 r->gpu_deflate ? (r->fused ? ", fused gpu deflate" : ", gpu deflate") : ", host zlib", busy, rd, gw,
-                 sw);
+                 r->gpu_deflate ? (r->fused ? ", fused gpu deflate" : ", gpu deflate") : ", host zlib",
+                 r->gpu_inflate ? ", gpu inflate of deflate landcover" : "", busy, rd, gw, sw);
         gcn10_log_message(log0, "INFO", msg, false);
     }
     exit_code = atomic_load(&r->fatal) ? 1 : 0;

@@ -381,3 +381,79 @@ int gcn10_raster_read_mt(gcn10_raster *r, int xoff, int yoff, int xcount, int yc
     }
     return 0;
 }
+
+void gcn10_read_plan_free(struct gcn10_read_plan *plan)
+{
+    for (int i = 0; i < plan->n_opened; i++)
+        gcn10_tiff_close_reader(plan->opened[i]);
+    free(plan->opened);
+    free(plan->chunks);
+    memset(plan, 0, sizeof *plan);
+}
+
+int gcn10_raster_plan_window(gcn10_raster *r, int xoff, int yoff, int xcount, int ycount,
+                             struct gcn10_read_plan *plan, char *err, size_t errcap)
+{
+    int rc = 0;
+
+    memset(plan, 0, sizeof *plan);
+    if (xoff < 0 || yoff < 0 || xcount <= 0 || ycount <= 0 || xoff + xcount > r->xsize ||
+        yoff + ycount > r->ysize) {
+        snprintf(err, errcap, "window %d,%d %dx%d outside raster %dx%d", xoff, yoff, xcount, ycount,
+                 r->xsize, r->ysize);
+        return -1;
+    }
+    if (r->tiff) {
+        rc = gcn10_tiff_plan_window(r->tiff, xoff, yoff, xcount, ycount, 0, 0, plan, err, errcap);
+        if (rc != 0)
+            gcn10_read_plan_free(plan);
+        return rc;
+    }
+    /* VRT: every source that touches the window.  The chunks of a plan are written
+     * concurrently, so sources that overlap inside the window (painted in file order by the
+     * host reader) are left to it; NODATA other than the 0 background too. */
+    for (int i = 0; i < r->n_src && rc == 0; i++) {
+        const struct vrt_source *s = &r->src[i];
+        int x0 = xoff > s->dx ? xoff : s->dx;
+        int y0 = yoff > s->dy ? yoff : s->dy;
+        int x1 = xoff + xcount < s->dx + s->w ? xoff + xcount : s->dx + s->w;
+        int y1 = yoff + ycount < s->dy + s->h ? yoff + ycount : s->dy + s->h;
+        struct gcn10_tiff *t, **g;
+
+        if (x0 >= x1 || y0 >= y1)
+            continue;
+        if (s->nodata > 0) {
+            rc = 1;
+            break;
+        }
+        for (int k = 0; k < i; k++) {
+            const struct vrt_source *o = &r->src[k];
+            int ox0 = x0 > o->dx ? x0 : o->dx, oy0 = y0 > o->dy ? y0 : o->dy;
+            int ox1 = x1 < o->dx + o->w ? x1 : o->dx + o->w, oy1 = y1 < o->dy + o->h ? y1 : o->dy + o->h;
+
+            if (ox0 < ox1 && oy0 < oy1)
+                rc = 1;
+        }
+        if (rc != 0)
+            break;
+        t = gcn10_tiff_open_reader(s->path, err, errcap);
+        if (!t) {
+            rc = -1;
+            break;
+        }
+        g = realloc(plan->opened, (size_t)(plan->n_opened + 1) * sizeof *g);
+        if (!g) {
+            gcn10_tiff_close_reader(t);
+            snprintf(err, errcap, "out of memory for the read plan");
+            rc = -1;
+            break;
+        }
+        plan->opened = g;
+        plan->opened[plan->n_opened++] = t;
+        rc = gcn10_tiff_plan_window(t, s->sx + (x0 - s->dx), s->sy + (y0 - s->dy), x1 - x0, y1 - y0,
+                                    x0 - xoff, y0 - yoff, plan, err, errcap);
+    }
+    if (rc != 0)
+        gcn10_read_plan_free(plan);
+    return rc;
+}

@@ -724,6 +724,72 @@ int gcn10_tiff_read_window(struct gcn10_tiff *t, int xoff, int yoff, int xcount,
     return gcn10_tiff_read_window_mt(t, xoff, yoff, xcount, ycount, dst, dst_stride, NULL, err, errcap);
 }
 
+/* The chunks of a window as they lie in the file, for the GPU decoder.  Mirrors the
+ * clipping of read_chunk(). */
+int gcn10_tiff_plan_window(struct gcn10_tiff *t, int xoff, int yoff, int xcount, int ycount, int dst_x,
+                           int dst_y, struct gcn10_read_plan *plan, char *err, size_t errcap)
+{
+    if ((t->compression != 8 && t->compression != 32946) || t->predictor == 2 || t->spp != 1 ||
+        t->bps != 8 || (uint64_t)t->cw * t->ch > ((uint64_t)1 << 28))
+        return 1;
+    if (xoff < 0 || yoff < 0 || xcount <= 0 || ycount <= 0 ||
+        (uint64_t)xoff + (uint64_t)xcount > t->width || (uint64_t)yoff + (uint64_t)ycount > t->height) {
+        snprintf(err, errcap, "window %d,%d %dx%d outside raster %ux%u", xoff, yoff, xcount, ycount,
+                 t->width, t->height);
+        return -1;
+    }
+    for (uint32_t cy = (uint32_t)yoff / t->ch; cy <= (uint32_t)(yoff + ycount - 1) / t->ch; cy++) {
+        for (uint32_t cx = (uint32_t)xoff / t->cw; cx <= (uint32_t)(xoff + xcount - 1) / t->cw; cx++) {
+            uint64_t idx = (uint64_t)cy * t->across + cx;
+            uint64_t off = t->offsets[idx], cnt = t->counts[idx];
+            uint32_t y_lo = cy * t->ch, x_lo = cx * t->cw;
+            uint32_t rows = t->tiled ? t->ch : (y_lo + t->ch <= t->height ? t->ch : t->height - y_lo);
+            uint32_t ys = (uint32_t)yoff > y_lo ? (uint32_t)yoff : y_lo;
+            uint32_t ye = (uint32_t)(yoff + ycount) < y_lo + rows ? (uint32_t)(yoff + ycount) : y_lo + rows;
+            uint32_t xs = (uint32_t)xoff > x_lo ? (uint32_t)xoff : x_lo;
+            uint32_t xe = (uint32_t)(xoff + xcount) < x_lo + t->cw ? (uint32_t)(xoff + xcount) : x_lo + t->cw;
+            struct gcn10_chunk_ref *c;
+
+            if (cnt == 0 || xs >= xe || ys >= ye)
+                continue;               /* sparse chunk: reads as zeros */
+            if (off > t->file_size || cnt > t->file_size - off) {
+                snprintf(err, errcap, "gdalrasterio error: a %s of the window %d,%d %dx%d lies outside the file",
+                         t->tiled ? "tile" : "strip", xoff, yoff, xcount, ycount);
+                return -1;
+            }
+            if (cnt > 0x7fffffffu)
+                return 1;
+            if (plan->n == plan->cap) {
+                size_t cap = plan->cap ? plan->cap * 2 : 256;
+                struct gcn10_chunk_ref *g = realloc(plan->chunks, cap * sizeof *g);
+
+                if (!g) {
+                    snprintf(err, errcap, "out of memory for the read plan");
+                    return -1;
+                }
+                plan->chunks = g;
+                plan->cap = cap;
+            }
+            c = &plan->chunks[plan->n++];
+            c->fd = t->fd;
+            c->file_off = off;
+            c->nbytes = (uint32_t)cnt;
+            c->chunk_w = t->cw;
+            c->rows = rows;
+            c->src_x = xs - x_lo;
+            c->src_y = ys - y_lo;
+            c->copy_w = xe - xs;
+            c->copy_h = ye - ys;
+            c->dst_x = (uint32_t)dst_x + (xs - (uint32_t)xoff);
+            c->dst_y = (uint32_t)dst_y + (ys - (uint32_t)yoff);
+            plan->covered += (uint64_t)c->copy_w * c->copy_h;
+            if (t->cw * rows > plan->max_chunk_bytes)
+                plan->max_chunk_bytes = t->cw * rows;
+        }
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------ */
 /* writer                                                                    */
 /* ------------------------------------------------------------------------ */
@@ -733,6 +799,7 @@ enum { TILE = 256 };        /* GDAL's default block size for TILED=YES */
 struct gcn10_tiff_writer {
     int fd;
     char *path;
+    char *part;                 /* the file is written under this name and renamed when complete */
     int xsize, ysize, across, down;
     double gt[6];
     gcn10_georef georef;        /* deep copy */
@@ -828,9 +895,13 @@ gcn10_tiff_writer *gcn10_tiff_create(const char *path, int xsize, int ysize, con
     w->offsets = calloc(nt, sizeof *w->offsets);
     w->counts = calloc(nt, sizeof *w->counts);
     w->path = strdup(path);
-    if (!w->offsets || !w->counts || !w->path || copy_georef(&w->georef, georef) != 0)
+    w->part = malloc(strlen(path) + 6);
+    if (w->part)
+        sprintf(w->part, "%s.part", path);
+    if (!w->offsets || !w->counts || !w->path || !w->part || copy_georef(&w->georef, georef) != 0)
         goto oom;
-    w->fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    /* an existing raster of that name stays as it is until this one is complete */
+    w->fd = open(w->part, O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (w->fd < 0 || write_all(w->fd, header, sizeof header, 0) != 0) {
         snprintf(err, errcap, "write error: cannot create %s: %s", path, strerror(errno));
         gcn10_tiff_abort(w);
@@ -1009,6 +1080,14 @@ done:
         rc = -1;
     }
     w->fd = -1;
+    if (rc == 0 && rename(w->part, w->path) != 0) {
+        snprintf(err, errcap, "write error on %s: %s", w->path, strerror(errno));
+        rc = -1;
+    }
+    if (rc == 0) {
+        free(w->part);
+        w->part = NULL;             /* nothing left for abort to remove */
+    }
     gcn10_tiff_abort(w);
     return rc;
 }
@@ -1019,6 +1098,9 @@ void gcn10_tiff_abort(gcn10_tiff_writer *w)
         return;
     if (w->fd >= 0)
         close(w->fd);
+    if (w->part)
+        unlink(w->part);            /* an unfinished raster is no raster */
+    free(w->part);
     free(w->offsets);
     free(w->counts);
     free(w->path);

@@ -99,6 +99,8 @@ typedef struct gcn10_config {
                                GPU straight from landcover + soil, no CN raster in HBM;
                                1 = CN strips in HBM, then encoded on the GPU per raster;
                                0 = raw strips are copied back, host zlib threads encode */
+    int gpu_inflate;        /* "gpu_inflate": 1 (default) DEFLATE-compressed landcover tiles cross PCIe
+                               compressed and are decoded on the GPU; 0 = on the host i/o pool */
 } gcn10_config;
 
 /* Returns 0; -1 cannot open (message in err); -2 a required key is missing

@@ -278,3 +278,88 @@ def test_compressed_tiles_spill_past_the_pinned_arena(tmp_path, tables):
         c, k = divmod(r, 9)
         p = tmp_path / ("cn_rasters_%s" % CONDS[c]) / ("cn_%s_%s_%d.tif" % (HCS[k // 3], ARCS[k % 3], bid))
         assert np.array_equal(np.array(Image.open(str(p))), want[r])
+
+
+def _check_block(tmp_path, esa, soil, tables, bid, bbox, esa_gt=ESA_GT, rasters=range(18)):
+    xo, yo, W, H, gt = oc.window(esa_gt, esa.shape[1], esa.shape[0], bbox)
+    sxo, syo, hsx, hsy, sgt = oc.window(SOIL_GT, soil.shape[1], soil.shape[0], bbox)
+    want = oc.process_block_mem(esa[yo:yo + H, xo:xo + W], gt, soil[syo:syo + hsy, sxo:sxo + hsx], sgt, tables)
+    for r in rasters:
+        c, k = divmod(r, 9)
+        p = tmp_path / ("cn_rasters_%s" % CONDS[c]) / ("cn_%s_%s_%d.tif" % (HCS[k // 3], ARCS[k % 3], bid))
+        assert np.array_equal(np.array(Image.open(str(p))), want[r]), p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gpu_inflate", [1, 0], ids=["gpu-inflate", "host-inflate"])
+@pytest.mark.parametrize("layout", ["tiles", "strips"])
+def test_deflate_landcover_decoded_on_the_gpu_or_the_host(tmp_path, tables, gpu_inflate, layout):
+    """DEFLATE landcover (tiles as in the ESA files, or strips): the compressed chunks go to the GPU
+    and are decoded there (gpu_inflate=1, default) or on the I/O pool (0); same rasters either way."""
+    esa, soil = _world(tmp_path, seed=77, extra_cfg="gpu_inflate=%d\n" % gpu_inflate)
+    if layout == "strips":
+        tiffutil.write_tiff(str(tmp_path / "esa.tif"), esa, gt=ESA_GT, compression=8, rows_per_strip=37)
+    (tmp_path / "ids.txt").write_text("101 103\n")
+    out = _run(tmp_path, "-c", "config.txt", "-l", "ids.txt")
+    assert out.returncode == 0, out.stderr[-2000:]
+    log = (tmp_path / "logs" / "rank_0.log").read_text()
+    assert ("gpu inflate of deflate landcover" in log) == bool(gpu_inflate)
+    for bid, *bbox in (BLOCKS[0], BLOCKS[2]):
+        _check_block(tmp_path, esa, soil, tables, bid, bbox)
+
+
+@pytest.mark.gpu
+def test_vrt_of_deflate_tiles_with_a_gap_decodes_on_the_gpu(tmp_path, tables):
+    """A mosaic of two DEFLATE tiles that leaves a strip of the block uncovered: the chunks of both
+    files are decoded on the GPU, the gap reads as 0 (the VRT's NoDataValue)."""
+    rng = np.random.default_rng(32)
+    esa = rng.choice(ESA_NASTY, size=(2000, 3000)).astype(np.uint8)
+    esa[esa == 0] = 10
+    esa[:, 1400:1500] = 0                               # nothing covers these columns
+    soil = rng.choice(HSG_NASTY, size=(82, 122)).astype(np.uint8)
+    (tmp_path / "tiles").mkdir()
+    tiffutil.write_tiff(str(tmp_path / "tiles" / "T_W.tif"), esa[:, :1400], compression=8, tile=(512, 512))
+    tiffutil.write_tiff(str(tmp_path / "tiles" / "T_E.tif"), esa[:, 1500:], compression=8, tile=(256, 128))
+    src = ""
+    for name, dx, w in (("T_W.tif", 0, 1400), ("T_E.tif", 1500, 1500)):
+        src += ('<ComplexSource resampling="nearest"><SourceFilename relativeToVRT="0">/vsicurl/https://example.invalid/'
+                'map/%s</SourceFilename><SourceBand>1</SourceBand><SrcRect xOff="0" yOff="0" xSize="%d" ySize="2000" />'
+                '<DstRect xOff="%d" yOff="0" xSize="%d" ySize="2000" /><NODATA>0</NODATA></ComplexSource>\n'
+                % (name, w, dx, w))
+    (tmp_path / "esa.vrt").write_text(
+        '<VRTDataset rasterXSize="3000" rasterYSize="2000">\n<GeoTransform> %r, %r, 0.0, %r, 0.0, %r</GeoTransform>\n'
+        '<VRTRasterBand dataType="Byte" band="1"><NoDataValue>0</NoDataValue>\n%s</VRTRasterBand></VRTDataset>\n'
+        % (ESA_GT[0], ESA_GT[1], ESA_GT[3], ESA_GT[5], src))
+    tiffutil.write_tiff(str(tmp_path / "soil.tif"), soil, gt=SOIL_GT, compression=5, rows_per_strip=8)
+    tiffutil.write_block_shapefile(str(tmp_path / "blocks"), [(7, 11.0, 48.5, 12.0, 49.5)])
+    (tmp_path / "config.txt").write_text(
+        "hysogs_data_path=%s\nesa_data_path=%s\nblocks_shp_path=%s\nlookup_table_path=%s\nlog_dir=%s\n"
+        "esa_tile_dir=%s\nstrip_rows=512\n" % (tmp_path / "soil.tif", tmp_path / "esa.vrt", tmp_path / "blocks.shp",
+                                               LOOKUPS, tmp_path / "logs", tmp_path / "tiles"))
+    out = _run(tmp_path, "-c", "config.txt")
+    assert out.returncode == 0, out.stderr[-2000:]
+    _check_block(tmp_path, esa, soil, tables, 7, [11.0, 48.5, 12.0, 49.5], rasters=(0, 5, 9, 17))
+
+
+@pytest.mark.gpu
+def test_corrupt_landcover_tile_fails_its_block_only(tmp_path, tables):
+    """A tile whose DEFLATE stream is damaged: the block that needs it is skipped with the
+    reference's load_raster failure lines and leaves no files; other blocks are written."""
+    esa, soil = _world(tmp_path, seed=78)
+    path = tmp_path / "esa.tif"
+    raw = bytearray(path.read_bytes())
+    im = Image.open(str(path))
+    offs, cnts = im.tag_v2[324], im.tag_v2[325]
+    across = (3000 + 511) // 512
+    k = 2 * across + 3                                  # tile (row 2, col 3): rows 1024.., columns 1536..: block 102 only
+    for i in range(offs[k] + 2, offs[k] + cnts[k]):
+        raw[i] = 0xFF
+    path.write_bytes(bytes(raw))
+    (tmp_path / "ids.txt").write_text("101 102\n")
+    out = _run(tmp_path, "-c", "config.txt", "-l", "ids.txt")
+    assert out.returncode == 0, out.stderr[-2000:]
+    log = (tmp_path / "logs" / "rank_0.log").read_text()
+    assert "gdalrasterio error: cannot decode a tile" in log
+    assert "esa load failed for block 102" in log
+    assert not (tmp_path / "cn_rasters_drained" / "cn_p_i_102.tif").exists()
+    _check_block(tmp_path, esa, soil, tables, 101, BLOCKS[0][1:])

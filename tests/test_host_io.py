@@ -27,15 +27,15 @@ def test_config_reference_file_shape(tmp_path):
     assert c["hysogs_data_path"] == "../../hsg/HYSOGs250m_4326_lzw.tif"
     assert c["esa_data_path"] == "../../landcover/esa_worldcover_2021.vrt"     # trimmed
     assert c["log_dir"] == "logs2/"                                            # last one wins
-    assert c["gpus"] == 0 and c["esa_tile_dir"] is None and c["gpu_deflate"] == 2
+    assert c["gpus"] == 0 and c["esa_tile_dir"] is None and c["gpu_deflate"] == 2 and c["gpu_inflate"] == 1
 
 
 def test_config_optional_keys_and_errors(tmp_path):
     p = tmp_path / "c.txt"
     base = "hysogs_data_path=a\nesa_data_path=b\nblocks_shp_path=c\nlookup_table_path=d\nlog_dir=e\n"
-    p.write_text(base + "workers_per_gpu=3\ngpus=4\nstrip_rows=512\nio_threads=3\ndeflate_level=1\nesa_tile_dir=/x\ngpu_deflate=0\n")
+    p.write_text(base + "workers_per_gpu=3\ngpus=4\nstrip_rows=512\nio_threads=3\ndeflate_level=1\nesa_tile_dir=/x\ngpu_deflate=0\ngpu_inflate=0\n")
     c = host.parse_config(str(p))
-    assert c["gpu_deflate"] == 0 and c["workers_per_gpu"] == 3
+    assert c["gpu_deflate"] == 0 and c["workers_per_gpu"] == 3 and c["gpu_inflate"] == 0
     assert (c["gpus"], c["strip_rows"], c["io_threads"], c["deflate_level"], c["esa_tile_dir"]) == \
         (4, 512, 3, 1, "/x")
     p.write_text("hysogs_data_path=a\nesa_data_path=b\n")

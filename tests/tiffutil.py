@@ -1,6 +1,7 @@
 """A small independent TIFF *producer* for reader tests (strips/tiles, none/deflate/LZW/
 packbits, predictor 2, big-endian, BigTIFF) and a shapefile producer."""
 import struct
+import os
 import zlib
 
 import numpy as np
@@ -117,7 +118,13 @@ def write_tiff(path, img, gt=None, compression=1, tile=None, rows_per_strip=None
             return b"".join(packbits_encode(bytes(r)) for r in c)
         raise ValueError(compression)
 
-    blobs = [enc(c) for c in chunks]
+    if compression in (8, 32946) and len(chunks) > 64:
+        # big synthetic worlds (tools/bench_pipeline.py): zlib releases the GIL
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:
+            blobs = list(ex.map(enc, chunks))
+    else:
+        blobs = [enc(c) for c in chunks]
     off_sz = 8 if bigtiff else 4
     hdr_len = 16 if bigtiff else 8
     pos = hdr_len

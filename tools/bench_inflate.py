@@ -26,18 +26,7 @@ def main():
     a = ap.parse_args()
     T = 1024
     side = 6 * T
-    if a.pattern == "natural":
-        # blobs of 4..64 px with 3 % of the pixels flipped: between the two synthetic extremes
-        rng = np.random.default_rng(7)
-        base, _, _, _ = bench.synth_block(1, side, "patches")
-        fine, _, _, _ = bench.synth_block(2, side // 8, "iid")
-        fine = np.repeat(np.repeat(fine, 8, axis=0), 8, axis=1)
-        pick = np.repeat(np.repeat(rng.random((side // 256, side // 256)) < 0.5, 256, axis=0), 256, axis=1)
-        esa = np.where(pick, base, fine)
-        noise, _, _, _ = bench.synth_block(3, side, "iid")
-        esa = np.where(rng.random((side, side)) < 0.03, noise, esa).astype(np.uint8)
-    else:
-        esa, _, _, _ = bench.synth_block(1, side, a.pattern)
+    esa, _, _, _ = bench.synth_block(1, side, a.pattern)
     tiles = [np.ascontiguousarray(esa[(k // 6) * T:(k // 6 + 1) * T, (k % 6) * T:(k % 6 + 1) * T]) for k in range(min(a.distinct, 36))]
     t0 = time.time()
     streams = [zlib.compress(t.tobytes(), a.level) for t in tiles]

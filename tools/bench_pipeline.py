@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--deflate-level", type=int, default=0)
     ap.add_argument("--gpu-deflate", type=int, default=2)
     ap.add_argument("--workers-per-gpu", type=int, default=0)
+    ap.add_argument("--gpu-inflate", type=int, default=1)
     ap.add_argument("--real-vrt-pixel", action="store_true",
                     help="use the shipped VRT's pixel size 8.3333333333330430e-05: 3-degree blocks become "
                          "36001 px wide (SURVEY.md section 7), rows are not 16-byte aligned")
@@ -60,9 +61,9 @@ def main():
     with open(os.path.join(wd, "config.txt"), "w") as f:
         f.write("hysogs_data_path=%s/soil.tif\nesa_data_path=%s/esa.tif\nblocks_shp_path=%s/blocks.shp\n"
                 "lookup_table_path=%s\nlog_dir=%s/logs\nstrip_rows=%d\ndeflate_level=%d\ngpu_deflate=%d\n"
-                "workers_per_gpu=%d\n"
+                "workers_per_gpu=%d\ngpu_inflate=%d\n"
                 % (wd, wd, wd, os.path.join(ROOT, "tests", "golden", "lookups"), wd, a.strip_rows,
-                   a.deflate_level, a.gpu_deflate, a.workers_per_gpu))
+                   a.deflate_level, a.gpu_deflate, a.workers_per_gpu, a.gpu_inflate))
     build_s = time.time() - t0
     run_modes(a, wd, size, nb, build_s)
 
@@ -85,7 +86,7 @@ def build_world(a, wd, size, nb, px):
 
 
 def run_modes(a, wd, size, nb, build_s):
-    res = {"size": size, "blocks": nb, "strip_rows": a.strip_rows, "gpus": a.gpus, "pattern": a.pattern, "gpu_deflate": a.gpu_deflate, "workers_per_gpu": a.workers_per_gpu, "esa_compression": a.esa_compression,
+    res = {"size": size, "blocks": nb, "strip_rows": a.strip_rows, "gpus": a.gpus, "pattern": a.pattern, "gpu_deflate": a.gpu_deflate, "gpu_inflate": a.gpu_inflate, "workers_per_gpu": a.workers_per_gpu, "esa_compression": a.esa_compression,
            "world_build_seconds": round(build_s, 1), "modes": {}}
     for mode in a.modes.split(","):
         env = dict(os.environ)
