@@ -180,6 +180,16 @@ def test_fused_encoder_awkward_tables(engine):
         np.repeat(np.repeat(small, 8, axis=0), 8, axis=1)[:H, :W]))
 
 
+@pytest.mark.parametrize("pattern", ["natural", "iid"])
+def test_fused_encoder_full_block_width(engine, tables, pattern):
+    """Two tile rows of a 36000-px wide block (141 tile positions across, the last one 160 px
+    wide), landcover of the bench patterns: all 5076 streams inflate to the oracle's rasters."""
+    import bench
+    esa, _, _, _ = bench.synth_block(3, 4096, pattern)
+    esa = np.ascontiguousarray(np.tile(esa[:512], (1, 9))[:, :36000])
+    _fused_case(engine, tables, 512, 36000, seed=21, nasty=False, coherent=False, esa_override=esa)
+
+
 def test_fused_vs_unfused_size(engine, tables):
     """The class-based match structure costs little compression against per-raster parsing."""
     H, W = 512, 768
