@@ -111,7 +111,23 @@ def cpu_baseline(workload: str, size: int):
                                              r["multi"]["worker_seconds_max"]),
         "single_core_value": round(r["single"]["gpx_per_s"], 4),
         "host_cores_available": r["cores_available"],
+        "host_cpu": _host_cpu(),
     }
+
+
+def _host_cpu():
+    """Model name and socket count of the box's host CPU (SURVEY.md 8d asks for them beside the baseline)."""
+    model, sockets = "", set()
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and not model:
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    sockets.add(line.split(":", 1)[1].strip())
+    except OSError:
+        pass
+    return {"model": model, "sockets": len(sockets) or None}
 
 
 def traffic_from_profiles(workload: str):
@@ -288,6 +304,7 @@ def main():
                          if (size == 36000 and strip == size and args.pattern == "iid") else None,
                          "kernel": kname, "algorithmic_bytes_per_launch": int(alg_bytes),
                          "avg_launch_ms": round(avg_launch_s * 1e3, 4),
+                         "median_launch_ms": round(float(np.median(kernel_ms)) / launches, 4),
                          "min_launch_ms": round(float(np.min(kernel_ms)) / launches, 4)},
             "cpu_baseline": cpu,
         }
