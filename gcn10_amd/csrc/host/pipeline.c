@@ -35,7 +35,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
-enum { TILE = 256, NBUF = 2, DEFAULT_STRIP_ROWS = 1024 };
+enum { TILE = 256, MAX_NBUF = 4, DEFAULT_NBUF = 3, DEFAULT_STRIP_ROWS = 1024 };
 
 struct run;
 
@@ -74,7 +74,7 @@ struct worker {
     gcn10_stream_t s_h2d, s_kernel, s_d2h;
     gcn10_raster *esa, *soil;
     size_t buf_px;                          /* capacity of one strip buffer, pixels */
-    struct strip_buf buf[NBUF];
+    struct strip_buf buf[MAX_NBUF];         /* the first run->nbuf are in use */
     uint8_t *d_coarse;
     size_t coarse_cap;
     int32_t *d_ci, *d_cj;
@@ -93,7 +93,8 @@ struct worker {
     size_t n_inflate;                       /* chunks of the block in flight */
     int blocks_done;
     double busy_seconds;
-    double t_read, t_gpu_wait, t_sink_wait, t_setup;   /* where the worker thread's time goes */
+    double t_read, t_gpu_wait, t_sink_wait;            /* where the worker thread's time goes */
+    double t_soil, t_create, t_finish, t_device;
 };
 
 struct run {
@@ -110,6 +111,7 @@ struct run {
     atomic_int next_block;
     atomic_int fatal;                       /* a worker hit an MPI_Abort-class error */
     int strip_rows;
+    int nbuf;                               /* strip buffer sets per worker (GCN10_STRIP_BUFFERS, 2..4) */
     int deflate_level;
     bool null_sink;                         /* GCN10_SINK=null: no compression, no files */
     bool gpu_deflate;                       /* tiles are encoded on the GPU */
@@ -342,7 +344,7 @@ static void free_strip_buffers(struct worker *w)
 {
     const struct gcn10_gpu_api *g = w->run->gpu;
 
-    for (int i = 0; i < NBUF; i++) {
+    for (int i = 0; i < w->run->nbuf; i++) {
         struct strip_buf *b = &w->buf[i];
 
         if (b->h_esa) g->host_free(w->ctx, b->h_esa);
@@ -379,7 +381,7 @@ static int ensure_strip_buffers(struct worker *w, int W)
     if (px <= w->buf_px)
         return 0;
     free_strip_buffers(w);
-    for (int i = 0; i < NBUF; i++) {
+    for (int i = 0; i < w->run->nbuf; i++) {
         struct strip_buf *b = &w->buf[i];
 
         GPU_TRY(w, g->host_alloc(w->ctx, px, (void **)&b->h_esa));
@@ -653,6 +655,7 @@ static int process_block(struct worker *w, int block_id)
     gcn10_tiff_writer *tifs[GCN10_N_RASTERS] = { 0 };
     int rc = 0, bi, n_strips;
     bool ok = false, inflated = false;
+    double t_mark = now_seconds();
 
     /* block geometry: attribute filter "ID"=<id>, first feature (src/cn.c:162-184) */
     bi = gcn10_blocks_find(&r->blocks, block_id);
@@ -689,12 +692,17 @@ static int process_block(struct worker *w, int block_id)
         rc = -1;
         goto out;
     }
-    if (gcn10_raster_read(w->soil, sxoff, syoff, hsx, hsy, coarse, err, sizeof err) != 0) {
+    t_mark = now_seconds();
+    /* the soil raster is a global file of full-width strips: a block's window touches ~1440 of
+     * them, decoded concurrently on the I/O pool and only as far as the window reaches */
+    if (gcn10_raster_read_mt(w->soil, sxoff, syoff, hsx, hsy, coarse, r->pool, err, sizeof err) != 0) {
         wlog(w, "ERROR", true, "%s", err);
         wlog(w, "ERROR", true, "hysogs load failed for block %d", block_id);
         goto out;
     }
     gcn10_build_index_maps(gt, soil_gt, W, H, hsx, hsy, ci, cj);       /* src/cn.c:218-229 */
+    w->t_soil += now_seconds() - t_mark;
+    t_mark = now_seconds();
 
     /* output directories (src/cn.c:237-256) and the 18 files */
     for (int c = 0; c < 2 && !r->null_sink; c++) {
@@ -719,6 +727,9 @@ static int process_block(struct worker *w, int block_id)
         }
     }
 
+    w->t_create += now_seconds() - t_mark;
+    t_mark = now_seconds();
+
     /* device side of the block */
     if (ensure_strip_buffers(w, W) != 0 ||
         ensure_dev(w, (void **)&w->d_coarse, &w->coarse_cap, (size_t)hsx * hsy) != 0 ||
@@ -738,6 +749,8 @@ static int process_block(struct worker *w, int block_id)
         goto out;
     }
 
+    w->t_device += now_seconds() - t_mark;
+
     /* DEFLATE landcover (the ESA tiles): compressed chunks -> HBM -> decoded there */
     w->n_inflate = 0;
     if (r->gpu_inflate) {
@@ -753,7 +766,7 @@ static int process_block(struct worker *w, int block_id)
      * (16-byte aligned strip starts for any W) */
     n_strips = (H + r->strip_rows - 1) / r->strip_rows;
     for (int s = 0; s < n_strips; s++) {
-        struct strip_buf *b = &w->buf[s % NBUF];
+        struct strip_buf *b = &w->buf[s % r->nbuf];
         int y0 = s * r->strip_rows;
         int rows = H - y0 < r->strip_rows ? H - y0 : r->strip_rows;
         size_t px = (size_t)W * (size_t)rows;
@@ -840,17 +853,17 @@ static int process_block(struct worker *w, int block_id)
         b->rows = rows;
 
         /* while this strip is in flight, hand the previous one to the sink */
-        if (s > 0 && drain_strip(w, &w->buf[(s - 1) % NBUF], tifs, W, H) != 0) {
+        if (s > 0 && drain_strip(w, &w->buf[(s - 1) % r->nbuf], tifs, W, H) != 0) {
             rc = -1;
             goto out;
         }
     }
-    for (int i = 0; i < NBUF; i++)
+    for (int i = 0; i < w->run->nbuf; i++)
         if (drain_strip(w, &w->buf[i], tifs, W, H) != 0) {
             rc = -1;
             goto out;
         }
-    for (int i = 0; i < NBUF; i++)
+    for (int i = 0; i < w->run->nbuf; i++)
         wait_sink(&w->buf[i]);
     ok = !atomic_load(&w->failed);
     if (inflated && w->n_inflate > 0) {
@@ -874,7 +887,7 @@ gpu_fail:
 
 out:
     /* nothing of this block may still be in flight when its buffers are reused */
-    for (int i = 0; i < NBUF; i++) {
+    for (int i = 0; i < w->run->nbuf; i++) {
         if (w->buf[i].d2h_issued) {
             g->event_sync(w->ctx, r->gpu_deflate ? w->buf[i].ev_meta : w->buf[i].ev_d2h);
             w->buf[i].d2h_issued = false;
@@ -883,6 +896,7 @@ out:
     }
     if (rc != 0 && w->ctx)
         g->device_sync(w->ctx);
+    t_mark = now_seconds();
     for (int k = 0; k < GCN10_N_RASTERS; k++) {
         if (!tifs[k])
             continue;
@@ -896,6 +910,7 @@ out:
         }
         tifs[k] = NULL;
     }
+    w->t_finish += now_seconds() - t_mark;
     if (ok || (r->null_sink && rc == 0 && !atomic_load(&w->failed))) {
         for (int k = 0; k < GCN10_N_RASTERS; k++) {
             /* src/cn.c:366-373: one completion line and one progress line per raster */
@@ -927,7 +942,7 @@ static void worker_teardown(struct worker *w)
     if (w->ctx) {
         g->device_sync(w->ctx);
         free_strip_buffers(w);
-        for (int i = 0; i < NBUF; i++) {
+        for (int i = 0; i < w->run->nbuf; i++) {
             struct strip_buf *b = &w->buf[i];
 
             if (b->ev_h2d) g->event_destroy(w->ctx, b->ev_h2d);
@@ -956,7 +971,7 @@ static void worker_teardown(struct worker *w)
     gcn10_raster_close(w->esa);
     gcn10_raster_close(w->soil);
     w->esa = w->soil = NULL;
-    for (int i = 0; i < NBUF; i++) {
+    for (int i = 0; i < w->run->nbuf; i++) {
         pthread_mutex_destroy(&w->buf[i].mu);
         pthread_cond_destroy(&w->buf[i].cv);
     }
@@ -1024,7 +1039,7 @@ static int worker_setup(struct worker *w)
     const struct gcn10_gpu_api *g = r->gpu;
     char err[1024];
 
-    for (int i = 0; i < NBUF; i++) {
+    for (int i = 0; i < w->run->nbuf; i++) {
         pthread_mutex_init(&w->buf[i].mu, NULL);
         pthread_cond_init(&w->buf[i].cv, NULL);
         w->buf[i].owner = w;
@@ -1044,7 +1059,7 @@ static int worker_setup(struct worker *w)
     GPU_TRY(w, g->stream_create(w->ctx, &w->s_d2h));
     GPU_TRY(w, g->event_create(w->ctx, &w->ev_comp));
     GPU_TRY(w, g->event_create(w->ctx, &w->ev_inflate));
-    for (int i = 0; i < NBUF; i++) {
+    for (int i = 0; i < w->run->nbuf; i++) {
         GPU_TRY(w, g->event_create(w->ctx, &w->buf[i].ev_h2d));
         GPU_TRY(w, g->event_create(w->ctx, &w->buf[i].ev_kernel));
         GPU_TRY(w, g->event_create(w->ctx, &w->buf[i].ev_d2h));
@@ -1168,6 +1183,12 @@ int gcn10_run(const gcn10_run_options *opt)
     r->gpu_deflate = r->cfg.gpu_deflate != 0;
     r->fused = r->cfg.gpu_deflate == 2;
     r->gpu_inflate = r->cfg.gpu_inflate != 0;
+    r->nbuf = DEFAULT_NBUF;
+    if (getenv("GCN10_STRIP_BUFFERS")) {
+        int n = atoi(getenv("GCN10_STRIP_BUFFERS"));
+
+        r->nbuf = n < 2 ? 2 : (n > MAX_NBUF ? MAX_NBUF : n);
+    }
 
     /* GPUs: one worker ("rank") each */
     r->gpu = gcn10_gpu_api_get(err, sizeof err);
@@ -1339,7 +1360,7 @@ int gcn10_run(const gcn10_run_options *opt)
     gcn10_log_message(log0, "INFO", msg, true);
     {
         int done_blocks = 0;
-        double busy = 0, rd = 0, gw = 0, sw = 0;
+        double busy = 0, rd = 0, gw = 0, sw = 0, so = 0, cr = 0, fi = 0, dv = 0;
 
         for (int i = 0; i < r->n_workers; i++) {
             done_blocks += r->workers[i].blocks_done;
@@ -1347,12 +1368,17 @@ int gcn10_run(const gcn10_run_options *opt)
             rd += r->workers[i].t_read;
             gw += r->workers[i].t_gpu_wait;
             sw += r->workers[i].t_sink_wait;
+            so += r->workers[i].t_soil;
+            cr += r->workers[i].t_create;
+            fi += r->workers[i].t_finish;
+            dv += r->workers[i].t_device;
         }
         snprintf(msg, sizeof msg, "timing: %d blocks, %.3f s wall, %d gpu worker(s)%s%s%s; worker seconds: "
-                 "in blocks %.3f, reading landcover %.3f, waiting for gpu %.3f, waiting for sink %.3f",
+                 "in blocks %.3f, reading landcover %.3f, waiting for gpu %.3f, waiting for sink %.3f, "
+                 "soil window %.3f, creating outputs %.3f, finishing outputs %.3f, device setup %.3f",
                  done_blocks, now_seconds() - t_start, r->n_workers, r->null_sink ? ", null sink" : "",
                  r->gpu_deflate ? (r->fused ? ", fused gpu deflate" : ", gpu deflate") : ", host zlib",
-                 r->gpu_inflate ? ", gpu inflate of deflate landcover" : "", busy, rd, gw, sw);
+                 r->gpu_inflate ? ", gpu inflate of deflate landcover" : "", busy, rd, gw, sw, so, cr, fi, dv);
         gcn10_log_message(log0, "INFO", msg, false);
     }
     exit_code = atomic_load(&r->fatal) ? 1 : 0;

@@ -543,15 +543,19 @@ static int packbits_decode(const unsigned char *src, size_t n, unsigned char *ds
     return 0;
 }
 
-/* decodes chunk `idx` into buf (cw*ch*spp bytes; strips may be shorter at the end) */
+/* decodes the first `need` bytes of chunk `idx` into buf (the chunk holds cw*rows*spp bytes;
+ * strips may be shorter at the end).  A window that ends early in a chunk -- a few columns of
+ * a full-width strip, as in the soil raster -- does not pay for the rest of it. */
 static int decode_chunk(struct gcn10_tiff *t, uint64_t idx, unsigned char *buf, size_t rawcap,
-                        unsigned char **scratch, size_t *scratch_cap, uint32_t rows_in_chunk)
+                        unsigned char **scratch, size_t *scratch_cap, uint32_t rows_in_chunk, size_t need)
 {
     uint64_t off = t->offsets[idx], cnt = t->counts[idx];
     size_t want = (size_t)t->cw * rows_in_chunk * t->spp;
 
     if (want > rawcap)
         return -1;
+    if (need < want)
+        want = need;
     if (off > t->file_size || cnt > t->file_size - off)
         return -1;                  /* chunk outside the file: corrupt directory */
     if (cnt == 0) {                 /* sparse tile: GDAL reads it as zeros */
@@ -594,10 +598,11 @@ static int decode_chunk(struct gcn10_tiff *t, uint64_t idx, unsigned char *buf, 
     if (t->predictor == 2) {        /* horizontal differencing, per row, per sample */
         size_t rowb = (size_t)t->cw * t->spp;
 
-        for (uint32_t r = 0; r < rows_in_chunk; r++) {
+        for (uint32_t r = 0; r < rows_in_chunk && (size_t)r * rowb < want; r++) {
             unsigned char *row = buf + (size_t)r * rowb;
+            size_t end = want - (size_t)r * rowb < rowb ? want - (size_t)r * rowb : rowb;
 
-            for (size_t i = t->spp; i < rowb; i++)
+            for (size_t i = t->spp; i < end; i++)
                 row[i] = (unsigned char)(row[i] + row[i - t->spp]);
         }
     }
@@ -642,8 +647,10 @@ static int read_chunk(const struct chunk_job *j)
         raw = g;
         raw_cap = rawcap;
     }
+    if (xs >= xe || ys >= ye)
+        return 0;
     if (decode_chunk(t, (uint64_t)j->cy * t->across + j->cx, raw, rawcap, &scratch, &scratch_cap,
-                     rows_in_chunk) != 0)
+                     rows_in_chunk, ((size_t)(ye - 1 - y_lo) * t->cw + (xe - x_lo)) * t->spp) != 0)
         return -1;
     for (uint32_t y = ys; y < ye; y++) {
         const unsigned char *s = raw + ((size_t)(y - y_lo) * t->cw + (xs - x_lo)) * t->spp;
