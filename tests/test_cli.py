@@ -363,3 +363,35 @@ def test_corrupt_landcover_tile_fails_its_block_only(tmp_path, tables):
     assert "esa load failed for block 102" in log
     assert not (tmp_path / "cn_rasters_drained" / "cn_p_i_102.tif").exists()
     _check_block(tmp_path, esa, soil, tables, 101, BLOCKS[0][1:])
+
+
+@pytest.mark.gpu
+def test_custom_lookups_with_more_than_256_pixel_classes(tmp_path):
+    """User-supplied lookup CSVs whose 18 rasters distinguish more than 256 (landcover, soil) pairs:
+    the fused encoder's class map does not exist, the program says so and encodes per raster."""
+    from oracle import cn_oracle_np as onp
+    esa, soil = _world(tmp_path, seed=91)
+    rng = np.random.default_rng(92)
+    lk = tmp_path / "lookups"
+    lk.mkdir()
+    tabs = []
+    for hc in onp.HCS:
+        for arc in onp.ARCS:
+            lines = ["grid_code,cn"]
+            for lc in sorted(set(range(64)) | set(int(v) for v in ESA_NASTY)):      # 64+ live classes x 8 soil pairs
+                for g in "ABCD":
+                    lines.append("%d_%s,%d" % (lc, g, int(rng.integers(0, 255))))
+            p = lk / ("default_lookup_%s_%s.csv" % (hc, arc))
+            p.write_text("\n".join(lines) + "\n")
+            t, bad = oc.load_lookup_table(str(p))
+            assert bad == 0
+            tabs.append(t)
+    tabs = np.stack(tabs)
+    cfg = (tmp_path / "config.txt").read_text().replace("lookup_table_path=%s" % LOOKUPS, "lookup_table_path=%s" % lk)
+    (tmp_path / "config.txt").write_text(cfg)
+    (tmp_path / "ids.txt").write_text("101\n")
+    out = _run(tmp_path, "-c", "config.txt", "-l", "ids.txt")
+    assert out.returncode == 0, out.stderr[-2000:]
+    log = (tmp_path / "logs" / "rank_0.log").read_text()
+    assert "more than 256 pixel classes" in log
+    _check_block(tmp_path, esa, soil, tabs, 101, BLOCKS[0][1:])
