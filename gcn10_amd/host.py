@@ -147,6 +147,20 @@ def read_blocks_shapefile(path: str):
     return ids, bbox
 
 
+class _ChunkRef(C.Structure):
+    """``struct gcn10_chunk_ref`` of csrc/host/host_internal.h."""
+    _fields_ = [("fd", C.c_int), ("file_off", C.c_uint64), ("nbytes", C.c_uint32), ("chunk_w", C.c_uint32),
+                ("rows", C.c_uint32), ("src_x", C.c_uint32), ("src_y", C.c_uint32), ("copy_w", C.c_uint32),
+                ("copy_h", C.c_uint32), ("dst_x", C.c_uint32), ("dst_y", C.c_uint32)]
+
+
+class _ReadPlan(C.Structure):
+    """``struct gcn10_read_plan`` of csrc/host/host_internal.h."""
+    _fields_ = [("chunks", C.POINTER(_ChunkRef)), ("n", C.c_size_t), ("cap", C.c_size_t),
+                ("opened", C.c_void_p), ("n_opened", C.c_int), ("covered", C.c_uint64),
+                ("max_chunk_bytes", C.c_uint32)]
+
+
 class Raster:
     """An open GeoTIFF / VRT (``gcn10_raster``)."""
 
@@ -170,6 +184,35 @@ class Raster:
 
     def georef_ptr(self):
         return lib().gcn10_raster_georef(self._h)
+
+    def plan(self, xoff, yoff, xcount, ycount):
+        """The read plan the pipeline hands to the GPU decoder (gcn10_raster_plan_window,
+        host_internal.h): None when the window has to go through the host reader, else
+        (chunks, covered_pixels, max_chunk_bytes) with chunks = list of dicts holding the
+        compressed bytes of a tile or strip and where its wanted part goes."""
+        plan = _ReadPlan()
+        err = C.create_string_buffer(1024)
+        L = lib()
+        L.gcn10_raster_plan_window.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.POINTER(_ReadPlan), C.c_char_p, C.c_size_t]
+        L.gcn10_raster_plan_window.restype = C.c_int
+        L.gcn10_read_plan_free.argtypes = [C.POINTER(_ReadPlan)]
+        L.gcn10_read_plan_free.restype = None
+        rc = L.gcn10_raster_plan_window(self._h, xoff, yoff, xcount, ycount, C.byref(plan), err, 1024)
+        if rc < 0:
+            raise HostError(err.value.decode())
+        if rc > 0:
+            return None
+        try:
+            chunks = []
+            for i in range(plan.n):
+                c = plan.chunks[i]
+                chunks.append({"data": os.pread(c.fd, c.nbytes, c.file_off), "chunk_w": c.chunk_w, "rows": c.rows,
+                               "src_x": c.src_x, "src_y": c.src_y, "copy_w": c.copy_w, "copy_h": c.copy_h,
+                               "dst_x": c.dst_x, "dst_y": c.dst_y})
+            return chunks, plan.covered, plan.max_chunk_bytes
+        finally:
+            L.gcn10_read_plan_free(C.byref(plan))
 
     def close(self):
         if self._h:

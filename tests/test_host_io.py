@@ -288,3 +288,85 @@ def test_save_raster_copies_input_georef(tmp_path):
 def test_save_raster_errors(tmp_path):
     with pytest.raises(host.HostError, match="write error"):
         host.save_raster(_img(1, 4, 4), GT, str(tmp_path / "no_such_dir" / "x.tif"))
+
+
+# ---- read plans for the GPU decoder (csrc/host/raster.c, tiff.c) ----------------------------
+
+def _assemble(plan, W, H):
+    import zlib
+    chunks, covered, max_bytes = plan
+    out = np.zeros((H, W), np.uint8)
+    seen = 0
+    for c in chunks:
+        raw = np.frombuffer(zlib.decompress(c["data"]), np.uint8)
+        assert raw.size >= c["chunk_w"] * c["rows"] and c["chunk_w"] * c["rows"] <= max_bytes
+        t = raw[:c["chunk_w"] * c["rows"]].reshape(c["rows"], c["chunk_w"])
+        out[c["dst_y"]:c["dst_y"] + c["copy_h"], c["dst_x"]:c["dst_x"] + c["copy_w"]] = \
+            t[c["src_y"]:c["src_y"] + c["copy_h"], c["src_x"]:c["src_x"] + c["copy_w"]]
+        seen += c["copy_w"] * c["copy_h"]
+    assert seen == covered
+    return out
+
+
+@pytest.mark.parametrize("kw", [dict(tile=(32, 16)), dict(tile=(64, 64)), dict(rows_per_strip=7), dict(),
+                                dict(tile=(16, 16), bigtiff=True), dict(rows_per_strip=3, big_endian=True)],
+                         ids=str)
+def test_read_plan_of_deflate_files_reassembles_every_window(tmp_path, kw):
+    """What the plan says (chunk bytes, clipping, placement), decoded here with stock zlib, equals
+    what the host reader returns for the same window."""
+    img = _img(7, 75, 101)
+    p = str(tmp_path / "t.tif")
+    tiffutil.write_tiff(p, img, gt=GT, compression=8, **kw)
+    with host.Raster(p) as r:
+        for (x, y, w, h) in [(0, 0, 101, 75), (13, 9, 50, 41), (100, 74, 1, 1), (31, 15, 2, 2), (0, 70, 101, 5)]:
+            plan = r.plan(x, y, w, h)
+            assert plan is not None and plan[1] == w * h
+            assert np.array_equal(_assemble(plan, w, h), img[y:y + h, x:x + w]), (x, y, w, h)
+        with pytest.raises(host.HostError):
+            r.plan(90, 0, 20, 5)
+
+
+@pytest.mark.parametrize("kw", [dict(compression=5), dict(compression=1), dict(compression=8, predictor=2),
+                                dict(compression=32773, rows_per_strip=9)], ids=str)
+def test_read_plan_declines_what_the_gpu_decoder_does_not_take(tmp_path, kw):
+    p = str(tmp_path / "t.tif")
+    tiffutil.write_tiff(p, _img(8, 40, 60), gt=GT, **kw)
+    with host.Raster(p) as r:
+        assert r.plan(0, 0, 60, 40) is None
+
+
+def test_read_plan_of_a_vrt_mosaic(tmp_path):
+    img = _img(9, 60, 90)
+    img[img == 0] = 7
+    tiffutil.write_tiff(str(tmp_path / "a.tif"), img[:, :40], compression=8, tile=(16, 16))
+    tiffutil.write_tiff(str(tmp_path / "b.tif"), img[:, 50:], compression=8, rows_per_strip=11)
+    tiffutil.write_tiff(str(tmp_path / "c.tif"), img[:, 30:60], compression=8, tile=(16, 16))
+
+    def vrt(sources):
+        body = ""
+        for name, dx, w, nodata in sources:
+            body += ('<ComplexSource><SourceFilename relativeToVRT="1">%s</SourceFilename><SourceBand>1</SourceBand>'
+                     '<SrcRect xOff="0" yOff="0" xSize="%d" ySize="60" /><DstRect xOff="%d" yOff="0" xSize="%d" '
+                     'ySize="60" />%s</ComplexSource>\n' % (name, w, dx, w, "<NODATA>%d</NODATA>" % nodata
+                                                            if nodata is not None else ""))
+        (tmp_path / "m.vrt").write_text(
+            '<VRTDataset rasterXSize="90" rasterYSize="60">\n<GeoTransform> 0.0, 1.0, 0.0, 0.0, 0.0, -1.0</GeoTransform>\n'
+            '<VRTRasterBand dataType="Byte" band="1"><NoDataValue>0</NoDataValue>\n%s</VRTRasterBand></VRTDataset>\n' % body)
+        return host.Raster(str(tmp_path / "m.vrt"))
+
+    want = img.copy()
+    want[:, 40:50] = 0                                  # the gap between a and b
+    with vrt([("a.tif", 0, 40, 0), ("b.tif", 50, 40, 0)]) as r:
+        for (x, y, w, h) in [(0, 0, 90, 60), (35, 5, 30, 50), (42, 0, 6, 60), (0, 0, 40, 60)]:
+            plan = r.plan(x, y, w, h)
+            assert plan is not None
+            assert np.array_equal(_assemble(plan, w, h), want[y:y + h, x:x + w])
+            assert np.array_equal(r.read(x, y, w, h), want[y:y + h, x:x + w])
+        assert r.plan(42, 0, 6, 60)[1] == 0             # nothing covers it: all background
+    # sources that overlap inside the window are painted in order by the host reader only
+    with vrt([("a.tif", 0, 40, 0), ("c.tif", 30, 30, 0), ("b.tif", 50, 40, 0)]) as r:
+        assert r.plan(0, 0, 90, 60) is None
+        assert r.plan(0, 0, 30, 60) is not None         # ... where they do not, the plan exists
+    # a NODATA other than the background value needs the host reader's transparency
+    with vrt([("a.tif", 0, 40, 7)]) as r:
+        assert r.plan(0, 0, 40, 60) is None
