@@ -1282,6 +1282,7 @@ struct FusedJob {
     uint8_t *tok;                   // [positions][kTileBytes] tokenised class tiles (F-A -> F-C)
     unsigned long long *tok_start;  // [positions][kTile][4]   where their match tokens start
     uint32_t hx_stride, hx_rows;
+    uint32_t diag;                  // gcn10_gpu_set_option("fused_diag"): timing experiments
     uint32_t n_sel;                 // selected rasters, ascending
     uint8_t sel[GCN10_N_RASTERS];
     TileJob t;
@@ -1551,28 +1552,70 @@ __global__ __launch_bounds__(kTile) void fused_stats_kernel(const FusedJob job)
     }
 }
 
-template <bool SMALL>
 struct SharedFC {
-    static constexpr int kWords = SMALL ? 8192 / 4 + 16 : kOutWords;
     uint8_t tile[kTile * kRowStride];   // token tile
-    uint32_t out[kWords];
-    uint32_t lenpack[288][kGroup / 2];  // code lengths of the group's rasters by class / length symbol,
-                                        // two rasters per dword
-    uint32_t cl[288];                   // current raster: code | length << 16
+    union {
+        struct {
+            uint32_t cl[288][8];            // code | length << 16 of the group's rasters, by class / length symbol
+            uint32_t lenpack[288][kGroup / 2];  // the lengths alone, two rasters per dword (row measure)
+        } c;
+        uint8_t class_of[gcn10::kClassCodes * 256];     // stored fallback only, after the walk
+    };
     uint32_t wave_sum[kGroup][4];
-    uint8_t class_of[SMALL ? 4 : gcn10::kClassCodes * 256];     // stored fallback only
 };
-constexpr int kFusedSmallStream = 8192;
 
-// pass F-C: one workgroup per (tile position, group of kGroup rasters).  The token tile
-// is loaded once; one walk over each row measures it for all rasters of the group (packed
-// 16-bit sums), a prefix sum places the rows, then each raster's stream is a walk that
-// only maps tokens to that raster's codes.
-template <bool SMALL>
+// A row's bits go straight into the stream's words in the arena: the words a row fills
+// completely are plain stores, its first and last (shared with the neighbouring rows, the
+// header or the trailer) are OR-ed into the zeroed slot.
+struct WordEmitter {
+    uint32_t *words;
+    uint32_t wpos;
+    unsigned long long acc;
+    uint32_t nacc;
+    bool first;
+    bool dry;
+    __device__ __forceinline__ void init(uint32_t *w, uint32_t start_bit)
+    {
+        dry = false;
+        words = w;
+        wpos = start_bit >> 5;
+        nacc = start_bit & 31u;
+        acc = 0ull;
+        first = true;
+    }
+    __device__ __forceinline__ void put(uint32_t value, uint32_t nbits)
+    {
+        acc |= (unsigned long long)value << nacc;
+        nacc += nbits;
+        if (nacc >= 32u) {
+            if (dry)
+                ;
+            else if (first)
+                atomicOr(&words[wpos], (uint32_t)acc);
+            else
+                words[wpos] = (uint32_t)acc;
+            first = false;
+            wpos++;
+            acc >>= 32;
+            nacc -= 32u;
+        }
+    }
+    __device__ __forceinline__ void finish()
+    {
+        if (nacc > 0u && !dry)
+            atomicOr(&words[wpos], (uint32_t)acc & (0xffffffffu >> (32u - nacc)));
+    }
+};
+
+// pass F-C: one workgroup per (tile position, group of kGroup rasters).  The token tile is
+// loaded once; one walk over each row measures it for all rasters of the group (packed
+// 16-bit sums), a prefix sum places the rows, and ONE more walk emits the row for all
+// rasters of the group at once: per token one LDS read of the group's codes, kGroup bit
+// accumulators in registers, words written straight to the arena (no stream image in LDS).
 __global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    SharedFC<SMALL> &sh = *reinterpret_cast<SharedFC<SMALL> *>(smem);
+    SharedFC &sh = *reinterpret_cast<SharedFC *>(smem);
     const int t = threadIdx.x;
     const uint32_t tiles = job.t.across * job.t.down;
     const uint32_t tix = blockIdx.x;
@@ -1581,19 +1624,30 @@ __global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
     const uint32_t nj = job.n_sel - j0 < (uint32_t)kGroup ? job.n_sel - j0 : (uint32_t)kGroup;
     const uint8_t *class_val = job.class_of + gcn10::kClassCodes * 256;
 
-    // anything to do for this tile position and group in this launch?
-    int any_stored;
+    // which rasters of the group have a slot, and which of those are stored
+    uint32_t live = 0, stored_mask = 0;
     {
         int mine = 0, st = 0;
         if ((uint32_t)t < nj) {
             const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)(j0 + t) * tiles + tix) * kBookBytes);
-            mine = ((b->stream_bytes <= (uint32_t)kFusedSmallStream) == SMALL) && b->slot != 0xffffffffu;
+            mine = b->slot != 0xffffffffu;
             st = mine && b->stream_bytes == (uint32_t)kMaxStream;
         }
-        if (!__syncthreads_or(mine))
+        live = (uint32_t)__ballot(mine);            // threads t < nj are all in wave 0: its ballots are the
+        stored_mask = (uint32_t)__ballot(st);       // masks, the other waves get them through LDS
+        if (t == 0) {
+            sh.wave_sum[0][0] = live;
+            sh.wave_sum[0][1] = stored_mask;
+        }
+        __syncthreads();
+        live = sh.wave_sum[0][0];
+        stored_mask = sh.wave_sum[0][1];
+        __syncthreads();
+        if (live == 0)
             return;
-        any_stored = __syncthreads_or(st);
     }
+    const uint32_t coded = live & ~stored_mask;     // rasters that get a Huffman stream
+
     // token tile and this row's match starts
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(job.tok + (size_t)tix * kTileBytes) + (t & 63);
@@ -1614,189 +1668,204 @@ __global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
         start[2] = src[2];
         start[3] = src[3];
     }
-    // code lengths of the group's rasters, by class (a literal of class c is the symbol val(c))
+    // codes of the group's rasters by class (a literal of class c is the symbol val(c)), the
+    // zeroed slots with their block headers, and per raster what is the same for every row
+    uint32_t *words[kGroup];
+    uint32_t header_bits[kGroup], dcode0[kGroup], dlen0[kGroup], dcode1[kGroup], dlen1[kGroup];
     uint32_t dist_pack[2][kGroup / 2] = {};
+#pragma unroll
+    for (int k = 0; k < kGroup; k++) {
+        words[k] = nullptr;
+        header_bits[k] = dcode0[k] = dlen0[k] = dcode1[k] = dlen1[k] = 0;
+        if (!((coded >> k) & 1u))
+            continue;
+        const uint32_t j = j0 + k;
+        const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)j * tiles + tix) * kBookBytes);
+        words[k] = reinterpret_cast<uint32_t *>(job.t.arena + b->slot);
+        header_bits[k] = b->header_bits;
+        dcode0[k] = b->dist_code[0];
+        dlen0[k] = b->dist_len[0];
+        dcode1[k] = (uint32_t)b->dist_code[1] | 63u << b->dist_len[1];      // + 6 extra bits: 256 - 193
+        dlen1[k] = (uint32_t)b->dist_len[1] + 6u;
+        dist_pack[0][k / 2] |= dlen0[k] << (16 * (k & 1));
+        dist_pack[1][k / 2] |= dlen1[k] << (16 * (k & 1));
+        const uint32_t n_words = (b->stream_bytes + 3u) / 4u;
+        for (uint32_t i = t; i < n_words; i += kTile)
+            words[k][i] = i < 64u ? b->header[i] : 0u;
+        for (int i = t; i < 288; i += kTile) {
+            const uint32_t sym = i < 256 ? class_val[job.sel[j] * 256 + i] : (uint32_t)i;
+            sh.c.cl[i][k] = (uint32_t)b->lit_code[sym] | (uint32_t)b->lit_len[sym] << 16;
+        }
+    }
+    __syncthreads();
     for (int i = t; i < 288; i += kTile) {
 #pragma unroll
         for (int k = 0; k < kGroup; k += 2) {
-            uint32_t pair = 0;
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                if ((uint32_t)(k + h) < nj) {
-                    const uint32_t j = j0 + k + h;
-                    const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)j * tiles + tix) * kBookBytes);
-                    const uint32_t sym = i < 256 ? class_val[job.sel[j] * 256 + i] : (uint32_t)i;
-                    pair |= (uint32_t)b->lit_len[sym] << (16 * h);
-                }
-            }
-            sh.lenpack[i][k / 2] = pair;
+            const uint32_t lo = ((coded >> k) & 1u) ? sh.c.cl[i][k] >> 16 : 0u;
+            const uint32_t hi = ((coded >> (k + 1)) & 1u) ? sh.c.cl[i][k + 1] >> 16 : 0u;
+            sh.c.lenpack[i][k / 2] = lo | hi << 16;
         }
     }
-#pragma unroll
-    for (int k = 0; k < kGroup; k++) {
-        if ((uint32_t)k < nj) {
-            const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)(j0 + k) * tiles + tix) * kBookBytes);
-            dist_pack[0][k / 2] |= (uint32_t)b->dist_len[0] << (16 * (k & 1));
-            dist_pack[1][k / 2] |= ((uint32_t)b->dist_len[1] + 6u) << (16 * (k & 1));
-        }
-    }
-    if (!SMALL && any_stored)
-        for (int i = t; i < gcn10::kClassCodes * 256 / 4; i += kTile)
-            reinterpret_cast<uint32_t *>(sh.class_of)[i] = reinterpret_cast<const uint32_t *>(job.class_of)[i];
+    __threadfence();                                // the zeroed slots are in place before any row ORs into them
     __syncthreads();
 
-    // bits of row t in every raster of the group
-    uint32_t acc[kGroup / 2] = {};
-    {
+    if (coded) {
         const uint8_t *row = sh.tile + t * kRowStride;
-        int x = 0;
-        while (x < kTile) {
-            const int p = next_set(start, x);
-            for (; x < p; x++) {
-                const uint32_t *lp = sh.lenpack[row[x]];
-#pragma unroll
-                for (int k = 0; k < kGroup / 2; k++)
-                    acc[k] += lp[k];
-            }
-            if (x >= kTile)
-                break;
-            const uint32_t b0 = row[x], b1 = row[x + 1], b2 = row[x + 2];
-            const uint32_t *lp = sh.lenpack[257u + (b0 & 31u)];
-            const uint32_t far = b0 >> 7;
-            const uint32_t common = (b1 >> 5) * 0x00010001u;
-#pragma unroll
-            for (int k = 0; k < kGroup / 2; k++)
-                acc[k] += lp[k] + common + (far ? dist_pack[1][k] : dist_pack[0][k]);
-            x += (int)b2 + 3;
-        }
-    }
-    // exclusive prefix over rows, all rasters of the group at once
-    uint32_t first_bit[kGroup];
-    {
-        uint32_t v[kGroup];
-        const int lane = t & 63;
-#pragma unroll
-        for (int k = 0; k < kGroup; k++) {
-            const uint32_t mine = (acc[k / 2] >> (16 * (k & 1))) & 0xffffu;
-            uint32_t s = mine;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t up = __shfl_up(s, off, 64);
-                if (lane >= off)
-                    s += up;
-            }
-            if (lane == 63)
-                sh.wave_sum[k][t >> 6] = s;
-            v[k] = s - mine;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kGroup; k++) {
-            uint32_t base = 0;
-            for (int w = 0; w < (t >> 6); w++)
-                base += sh.wave_sum[k][w];
-            first_bit[k] = v[k] + base;
-        }
-    }
-    uint8_t *o = reinterpret_cast<uint8_t *>(sh.out);
-
-#pragma unroll
-    for (int k = 0; k < kGroup; k++) {
-        if ((uint32_t)k >= nj)
-            break;
-        const uint32_t j = j0 + k;
-        const Book *book = reinterpret_cast<const Book *>(job.t.books + ((size_t)j * tiles + tix) * kBookBytes);
-        const uint32_t stream_bytes = book->stream_bytes;
-        const uint32_t slot = book->slot;
-        if (((stream_bytes <= (uint32_t)kFusedSmallStream) != SMALL) || slot == 0xffffffffu)
-            continue;                               // block-uniform
-        const bool stored = stream_bytes == (uint32_t)kMaxStream;
-        const uint32_t n_words = (stream_bytes + 3) / 4;
-        const uint32_t header_bits = book->header_bits;
-        const uint32_t adler = job.t.hist[((size_t)j * tiles + tix) * kHistWords + 290];
-
-        __syncthreads();                            // the previous raster's image has been copied out
-        for (uint32_t i = t; i < n_words + 1; i += kTile)
-            sh.out[i] = (i < 64 && !stored) ? book->header[i] : 0u;
+        // bits of row t in every raster of the group
+        uint32_t acc[kGroup / 2] = {};
         {
-            const uint32_t v = class_val[job.sel[j] * 256 + t];     // value of class t in this raster
-            sh.cl[t] = (uint32_t)book->lit_code[v] | (uint32_t)book->lit_len[v] << 16;
-            if (t < 32)
-                sh.cl[256 + t] = (uint32_t)book->lit_code[256 + t] | (uint32_t)book->lit_len[256 + t] << 16;
-        }
-        const uint32_t dcode0 = book->dist_code[0], dlen0 = book->dist_len[0];
-        const uint32_t dcode1 = (uint32_t)book->dist_code[1] | 63u << book->dist_len[1];    // + 6 extra bits: 256 - 193
-        const uint32_t dlen1 = (uint32_t)book->dist_len[1] + 6u;
-        __syncthreads();
-
-        if (!stored) {
-            RowEmitter em{ sh.out, header_bits + first_bit[k], 0ull, 0 };
-            const uint8_t *row = sh.tile + t * kRowStride;
-            int x = 0;
+            int x = (job.diag & 4u) ? kTile : 0;
             while (x < kTile) {
                 const int p = next_set(start, x);
                 for (; x < p; x++) {
-                    const uint32_t c = sh.cl[row[x]];
-                    em.put(c & 0xffffu, (int)(c >> 16));
+                    const uint32_t *lp = sh.c.lenpack[row[x]];
+#pragma unroll
+                    for (int k = 0; k < kGroup / 2; k++)
+                        acc[k] += lp[k];
                 }
                 if (x >= kTile)
                     break;
                 const uint32_t b0 = row[x], b1 = row[x + 1], b2 = row[x + 2];
-                const uint32_t c = sh.cl[257u + (b0 & 31u)];
-                const uint32_t l = c >> 16;
-                em.put((c & 0xffffu) | (b1 & 31u) << l, (int)(l + (b1 >> 5)));     // <= 15 + 5 bits
-                if (b0 >> 7)
-                    em.put(dcode1, (int)dlen1);                                     // <= 15 + 6 bits
-                else
-                    em.put(dcode0, (int)dlen0);
+                const uint32_t *lp = sh.c.lenpack[257u + (b0 & 31u)];
+                const uint32_t far = b0 >> 7;
+                const uint32_t common = (b1 >> 5) * 0x00010001u;
+#pragma unroll
+                for (int k = 0; k < kGroup / 2; k++)
+                    acc[k] += lp[k] + common + (far ? dist_pack[1][k] : dist_pack[0][k]);
                 x += (int)b2 + 3;
             }
-            if (t == kTile - 1)
-                em.put(sh.cl[256] & 0xffffu, (int)(sh.cl[256] >> 16));             // end of block
-            em.finish();
         }
-        else if (!SMALL) {
-            // stored fallback: the raster's bytes are val(class), two blocks of 32768 bytes;
-            // the classes are formed again from landcover + soil (the tile in LDS holds tokens)
-            if (t == 0) {
-                o[0] = 0x78;
-                o[1] = 0x01;
-                for (int b = 0; b < 2; b++) {
-                    uint8_t *h = o + 2 + b * (5 + 32768);
-                    h[0] = (uint8_t)(b == 1);
-                    h[1] = 0x00;
-                    h[2] = 0x80;
-                    h[3] = 0xff;
-                    h[4] = 0x7f;
+        // exclusive prefix over rows, all rasters of the group at once
+        uint32_t first_bit[kGroup];
+        {
+            uint32_t v[kGroup];
+            const int lane = t & 63;
+#pragma unroll
+            for (int k = 0; k < kGroup; k++) {
+                const uint32_t mine = (acc[k / 2] >> (16 * (k & 1))) & 0xffffu;
+                uint32_t s = mine;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t up = __shfl_up(s, off, 64);
+                    if (lane >= off)
+                        s += up;
+                }
+                if (lane == 63)
+                    sh.wave_sum[k][t >> 6] = s;
+                v[k] = s - mine;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kGroup; k++) {
+                uint32_t base = 0;
+                for (int w = 0; w < (t >> 6); w++)
+                    base += sh.wave_sum[k][w];
+                first_bit[k] = v[k] + base;
+            }
+        }
+        // the row, for every raster of the group in one walk
+        WordEmitter em[kGroup];
+#pragma unroll
+        for (int k = 0; k < kGroup; k++) {
+            em[k].init(words[k], header_bits[k] + first_bit[k]);
+            em[k].dry = (job.diag & 1u) != 0;
+        }
+        int x = (job.diag & 2u) ? kTile : 0;
+        while (x < kTile) {
+            const int p = next_set(start, x);
+            for (; x < p; x++) {
+                const uint32_t *cl = sh.c.cl[row[x]];
+#pragma unroll
+                for (int k = 0; k < kGroup; k++) {
+                    if ((coded >> k) & 1u) {
+                        const uint32_t c = cl[k];
+                        em[k].put(c & 0xffffu, c >> 16);
+                    }
                 }
             }
-            const uint8_t *val = class_val + job.sel[j] * 256;
-            const uint32_t xc = (uint32_t)(t & 63) * 4u;
-            for (int i = 0; i < kTile / 4; i++) {
-                const int r = i * 4 + (t >> 6);
-                const uint32_t c4 = class_pixels4(job, tx * kTile + xc, ty * kTile + (uint32_t)r, sh.class_of);
-                uint8_t *dst = o + 2 + (r >> 7) * (5 + 32768) + 5 + (r & 127) * kTile + xc;
-                dst[0] = val[c4 & 0xffu];
-                dst[1] = val[(c4 >> 8) & 0xffu];
-                dst[2] = val[(c4 >> 16) & 0xffu];
-                dst[3] = val[c4 >> 24];
+            if (x >= kTile)
+                break;
+            const uint32_t b0 = row[x], b1 = row[x + 1], b2 = row[x + 2];
+            const uint32_t *cl = sh.c.cl[257u + (b0 & 31u)];
+            const bool far = (b0 >> 7) != 0;
+#pragma unroll
+            for (int k = 0; k < kGroup; k++) {
+                if ((coded >> k) & 1u) {
+                    const uint32_t c = cl[k];
+                    const uint32_t l = c >> 16;
+                    em[k].put((c & 0xffffu) | (b1 & 31u) << l, l + (b1 >> 5));      // <= 15 + 5 bits
+                    em[k].put(far ? dcode1[k] : dcode0[k], far ? dlen1[k] : dlen0[k]);  // <= 15 + 6 bits
+                }
+            }
+            x += (int)b2 + 3;
+        }
+#pragma unroll
+        for (int k = 0; k < kGroup; k++) {
+            if ((coded >> k) & 1u) {
+                if (t == kTile - 1) {
+                    const uint32_t c = sh.c.cl[256][k];
+                    em[k].put(c & 0xffffu, c >> 16);                               // end of block
+                }
+                em[k].finish();
             }
         }
-        __syncthreads();
+    }
+    // trailers: the Adler-32 of the raster's tile, big endian, after the last (padded) byte
+    if ((uint32_t)t < nj && ((coded >> t) & 1u)) {
+        const uint32_t j = j0 + (uint32_t)t;
+        const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)j * tiles + tix) * kBookBytes);
+        const uint32_t adler = job.t.hist[((size_t)j * tiles + tix) * kHistWords + 290];
+        uint32_t *w = reinterpret_cast<uint32_t *>(job.t.arena + b->slot);
+        const uint32_t at = b->stream_bytes - 4u;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            const uint32_t byte = (adler >> (24 - 8 * i)) & 0xffu;
+            atomicOr(&w[(at + i) >> 2], byte << (8 * ((at + i) & 3u)));
+        }
+    }
+    if (stored_mask == 0)
+        return;
+
+    // stored fallback (incompressible tiles): the raster's bytes are val(class), two blocks of
+    // 32768 bytes; the classes are formed again from landcover + soil (the tile in LDS holds tokens)
+    __syncthreads();
+    for (int i = t; i < gcn10::kClassCodes * 256 / 4; i += kTile)
+        reinterpret_cast<uint32_t *>(sh.class_of)[i] = reinterpret_cast<const uint32_t *>(job.class_of)[i];
+    __syncthreads();
+    for (uint32_t k = 0; k < nj; k++) {
+        if (!((stored_mask >> k) & 1u))
+            continue;
+        const uint32_t j = j0 + k;
+        const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)j * tiles + tix) * kBookBytes);
+        uint8_t *o = job.t.arena + b->slot;
+        const uint32_t adler = job.t.hist[((size_t)j * tiles + tix) * kHistWords + 290];
         if (t == 0) {
-            const uint32_t at = stream_bytes - 4;
+            o[0] = 0x78;
+            o[1] = 0x01;
+            for (int blk = 0; blk < 2; blk++) {
+                uint8_t *h = o + 2 + blk * (5 + 32768);
+                h[0] = (uint8_t)(blk == 1);
+                h[1] = 0x00;
+                h[2] = 0x80;
+                h[3] = 0xff;
+                h[4] = 0x7f;
+            }
+            const uint32_t at = (uint32_t)kMaxStream - 4u;
             o[at] = (uint8_t)(adler >> 24);
             o[at + 1] = (uint8_t)(adler >> 16);
             o[at + 2] = (uint8_t)(adler >> 8);
             o[at + 3] = (uint8_t)adler;
         }
-        __syncthreads();
-        {
-            const uint32_t nvec = (stream_bytes + 15) / 16;
-            u32x4 *dst = reinterpret_cast<u32x4 *>(job.t.arena + slot);
-            const u32x4 *srcv = reinterpret_cast<const u32x4 *>(sh.out);
-            for (uint32_t i = t; i < nvec; i += kTile)
-                dst[i] = srcv[i];
+        const uint8_t *val = class_val + job.sel[j] * 256;
+        const uint32_t xc = (uint32_t)(t & 63) * 4u;
+        for (int i = 0; i < kTile / 4; i++) {
+            const int r = i * 4 + (t >> 6);
+            const uint32_t c4 = class_pixels4(job, tx * kTile + xc, ty * kTile + (uint32_t)r, sh.class_of);
+            uint8_t *dst = o + 2 + (r >> 7) * (5 + 32768) + 5 + (r & 127) * kTile + xc;
+            dst[0] = val[c4 & 0xffu];
+            dst[1] = val[(c4 >> 8) & 0xffu];
+            dst[2] = val[(c4 >> 16) & 0xffu];
+            dst[3] = val[c4 >> 24];
         }
     }
 }
@@ -1930,6 +1999,7 @@ int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W,
     job.class_of = ctx->d_class_of;
     job.hx_stride = ctx->hx_stride;
     job.hx_rows = ctx->hx_rows;
+    job.diag = (uint32_t)ctx->fused_diag;
     for (int r = 0; r < GCN10_N_RASTERS; r++)
         if ((cond_mask >> (r / 9)) & 1u && (table_mask >> (r % 9)) & 1u)
             job.sel[job.n_sel++] = (uint8_t)r;
@@ -1963,15 +2033,12 @@ int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W,
     job.tok_start = reinterpret_cast<unsigned long long *>(job.tok + (size_t)positions * kTileBytes);
 
     static_assert(sizeof(SharedFA) <= 80 * 1024, "two fused statistics workgroups per CU");
-    static_assert(sizeof(SharedFC<true>) <= 80 * 1024, "two small-stream fused emit workgroups per CU");
-    static_assert(sizeof(SharedFC<false>) <= 160 * 1024, "fused emit pass must fit LDS");
+    static_assert(sizeof(SharedFC) <= 80 * 1024, "two fused emit workgroups per CU");
     if (!ctx->fused_ready) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_stats_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SharedFA)));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_emit_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SharedFC<true>)));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_emit_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SharedFC<false>)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_emit_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SharedFC)));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(deflate_codes_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(sizeof(Work) * kBuildThreads)));
@@ -1988,9 +2055,7 @@ int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W,
         hipLaunchKernelGGL(deflate_codes_kernel, dim3(((uint32_t)nblocks + kBuildThreads - 1) / kBuildThreads),
                            dim3(kBuildThreads), sizeof(Work) * kBuildThreads, s, job.t);
     const uint32_t groups = (job.n_sel + kGroup - 1) / kGroup;
-    hipLaunchKernelGGL(fused_emit_kernel<true>, dim3(positions, groups), dim3(kTile), sizeof(SharedFC<true>), s, job);
-    hipLaunchKernelGGL(fused_emit_kernel<false>, dim3(positions, groups), dim3(kTile), sizeof(SharedFC<false>), s,
-                       job);
+    hipLaunchKernelGGL(fused_emit_kernel, dim3(positions, groups), dim3(kTile), sizeof(SharedFC), s, job);
     HIP_TRY(hipGetLastError());
     return GCN10_OK;
 }

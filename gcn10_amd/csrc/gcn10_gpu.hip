@@ -1393,6 +1393,8 @@ int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value)
         ctx->xcd_slabs = value;
     else if (!strcmp(name, "deflate_wave_codes") && (value == 0 || value == 1))
         ctx->deflate_wave_codes = value;
+    else if (!strcmp(name, "fused_diag") && value >= 0 && value < 8)
+        ctx->fused_diag = value;
     else if (!strcmp(name, "prefetch") && (value == -1 || value == 0 || value == 1))
         ctx->prefetch = value;
     else
