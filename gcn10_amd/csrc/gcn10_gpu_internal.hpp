@@ -61,6 +61,7 @@ struct gcn10_gpu_ctx {
     int fused_diag = 0;             // timing experiments only (streams become invalid): 1 no word stores,
                                     // 2 no emit walk, 4 no measure walk
     bool fused_ready = false;
+    bool codes_ready = false;       // LDS attribute of the per-thread code construction set
     bool deflate_ready = false;     // LDS attributes of the tile encoder set on this device
     void *deflate_ws = nullptr;     // per-tile statistics + code books of the tile encoder
     size_t deflate_ws_cap = 0;
