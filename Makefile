@@ -25,10 +25,10 @@ oracle:
 	$(MAKE) -C oracle
 
 GPUSRC := $(wildcard $(CSRC)/*.hip)
-$(PKG)/libgcn10_gpu.so: $(GPUSRC) $(CSRC)/gcn10_gpu_internal.hpp include/gcn10_gpu.h
+$(PKG)/libgcn10_gpu.so: $(GPUSRC) $(wildcard $(CSRC)/*.hpp) include/gcn10_gpu.h
 	$(HIPCC) $(HIPFLAGS) -I$(CSRC) -shared -o $@ $(GPUSRC)
 
-$(PKG)/libgcn10_host.so: $(HOSTLIBSRC) include/gcn10_host.h include/gcn10_gpu.h
+$(PKG)/libgcn10_host.so: $(HOSTLIBSRC) $(CSRC)/host/host_internal.h include/gcn10_host.h include/gcn10_gpu.h
 	$(CC) $(CFLAGS) -shared -o $@ $(HOSTLIBSRC) -lm -lz -ldl
 
 ifneq ($(wildcard $(CSRC)/host/main.c),)
