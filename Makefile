@@ -28,7 +28,7 @@ GPUSRC := $(wildcard $(CSRC)/*.hip)
 $(PKG)/libgcn10_gpu.so: $(GPUSRC) $(wildcard $(CSRC)/*.hpp) include/gcn10_gpu.h
 	$(HIPCC) $(HIPFLAGS) -I$(CSRC) -shared -o $@ $(GPUSRC)
 
-$(PKG)/libgcn10_host.so: $(HOSTLIBSRC) $(CSRC)/host/host_internal.h include/gcn10_host.h include/gcn10_gpu.h
+$(PKG)/libgcn10_host.so: $(HOSTLIBSRC) $(wildcard $(CSRC)/host/*.h) include/gcn10_host.h include/gcn10_gpu.h
 	$(CC) $(CFLAGS) -shared -o $@ $(HOSTLIBSRC) -lm -lz -ldl
 
 ifneq ($(wildcard $(CSRC)/host/main.c),)

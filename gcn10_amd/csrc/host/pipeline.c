@@ -18,8 +18,7 @@
  * static `i += size` round-robin, src/main.c:171, made dynamic); no data moves
  * between GPUs, so there is no collective and no RCCL.
  */
-#include "gcn10_host.h"
-#include "host_internal.h"
+#include "pipeline_internal.h"
 
 #include <errno.h>
 #include <limits.h>
@@ -35,93 +34,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
-enum { TILE = 256, MAX_NBUF = 4, DEFAULT_NBUF = 3, DEFAULT_STRIP_ROWS = 1024 };
-
-struct run;
-
-/* one rotating set of strip buffers */
-struct strip_buf {
-    uint8_t *h_esa;                         /* pinned */
-    uint8_t *d_esa;
-    uint8_t *h_out[GCN10_N_RASTERS];        /* pinned */
-    uint8_t *d_out[GCN10_N_RASTERS];
-    gcn10_event_t ev_h2d, ev_kernel, ev_d2h, ev_meta;
-    /* GPU-side DEFLATE: compressed tiles of all 18 rasters of the strip */
-    uint8_t *d_arena, *h_arena;             /* h_arena pinned */
-    size_t arena_cap;                       /* device arena: the encoder's worst case      */
-    size_t h_arena_cap;                     /* pinned arena: an eighth of it (>= 32 MB)    */
-    uint8_t *h_spill;                       /* pageable stand-in when a strip needs more   */
-    const uint8_t *h_tiles;                 /* where this strip's streams are: arena or spill */
-    uint32_t *d_table, *h_table;            /* [18][tiles][2]; h_table pinned */
-    unsigned long long *d_cursor, *h_cursor;
-    const uint8_t **d_ptrs;                 /* device array of the 18 d_out pointers */
-    /* compression jobs of the strip currently held by this buffer */
-    pthread_mutex_t mu;
-    pthread_cond_t cv;
-    int pending;
-    bool d2h_issued;
-    int y0, rows;                           /* strip held */
-    struct worker *owner;
-};
-
-struct worker {
-    struct run *run;
-    int rank;                               /* "rank" in the logs: outer_rank * n_workers + index */
-    int index;                              /* worker index in this process; GPU = index % n_devices */
-    pthread_t thread;
-    gcn10_log *log;
-    gcn10_gpu_ctx *ctx;
-    gcn10_stream_t s_h2d, s_kernel, s_d2h;
-    gcn10_raster *esa, *soil;
-    size_t buf_px;                          /* capacity of one strip buffer, pixels */
-    struct strip_buf buf[MAX_NBUF];         /* the first run->nbuf are in use */
-    uint8_t *d_coarse;
-    size_t coarse_cap;
-    int32_t *d_ci, *d_cj;
-    size_t ci_cap, cj_cap;
-    atomic_bool failed;                     /* a sink job of the current block failed */
-    bool fused;                             /* this worker's tables allow the fused encoder */
-    /* landcover decoded on the GPU (gpu_inflate): the block's compressed chunks and where they go */
-    uint8_t *h_comp, *d_comp;               /* h_comp pinned */
-    size_t h_comp_cap, d_comp_cap;
-    gcn10_inflate_tile *h_jobs, *d_jobs;    /* h_jobs pinned */
-    uint32_t *h_status, *d_status;          /* h_status pinned */
-    size_t jobs_cap;
-    uint8_t *d_block;                       /* the decoded landcover block, W x H */
-    size_t block_cap;
-    gcn10_event_t ev_comp, ev_inflate;
-    size_t n_inflate;                       /* chunks of the block in flight */
-    int blocks_done;
-    double busy_seconds;
-    double t_read, t_gpu_wait, t_sink_wait;            /* where the worker thread's time goes */
-    double t_soil, t_create, t_finish, t_device;
-};
-
-struct run {
-    gcn10_config cfg;
-    gcn10_run_options opt;
-    const struct gcn10_gpu_api *gpu;
-    gcn10_blocks blocks;
-    int *block_ids;
-    int n_blocks;
-    int tables[9][256][5];
-    int n_workers;
-    struct worker *workers;
-    gcn10_pool *pool;
-    atomic_int next_block;
-    atomic_int fatal;                       /* a worker hit an MPI_Abort-class error */
-    int strip_rows;
-    int nbuf;                               /* strip buffer sets per worker (GCN10_STRIP_BUFFERS, 2..4) */
-    int deflate_level;
-    bool null_sink;                         /* GCN10_SINK=null: no compression, no files */
-    bool gpu_deflate;                       /* tiles are encoded on the GPU */
-    bool fused;                             /* ... straight from landcover + soil (no CN rasters in HBM) */
-    bool gpu_inflate;                       /* DEFLATE landcover tiles are decoded on the GPU */
-    int n_devices;                          /* visible GPUs; worker i uses device i % n_devices */
-    int outer_rank, outer_size;             /* this process among the processes of an mpirun / srun */
-};
-
-static double now_seconds(void)
+double gcn10_now_seconds(void)
 {
     struct timespec ts;
 
@@ -129,10 +42,7 @@ static double now_seconds(void)
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-static void wlog(struct worker *w, const char *level, bool console, const char *fmt, ...)
-    __attribute__((format(printf, 4, 5)));
-
-static void wlog(struct worker *w, const char *level, bool console, const char *fmt, ...)
+void gcn10_wlog(struct worker *w, const char *level, bool console, const char *fmt, ...)
 {
     char msg[8192];                         /* char msg[8192], src/cn.c:144 */
     va_list ap;
@@ -142,6 +52,10 @@ static void wlog(struct worker *w, const char *level, bool console, const char *
     va_end(ap);
     gcn10_log_message(w->log, level, msg, console);
 }
+
+#define now_seconds gcn10_now_seconds
+#define wlog gcn10_wlog
+#define ensure_dev gcn10_ensure_dev
 
 /* ------------------------------------------------------------------------ */
 /* sink: tile compression jobs                                               */
@@ -421,7 +335,7 @@ static int ensure_strip_buffers(struct worker *w, int W)
     return 0;
 }
 
-static int ensure_dev(struct worker *w, void **p, size_t *cap, size_t need)
+int gcn10_ensure_dev(struct worker *w, void **p, size_t *cap, size_t need)
 {
     const struct gcn10_gpu_api *g = w->run->gpu;
 
@@ -454,190 +368,6 @@ static void output_path(char *out, size_t cap, const char *cond, const char *hc,
             snprintf(out, cap, "cn_rasters_%s/cn_%s_%s_%d_.tif", cond, hc, arc, block_id); /* :341 */
         }
     }
-}
-
-/* compressed chunks of a read plan -> pinned staging, a slice per pool job */
-struct comp_job {
-    const struct gcn10_chunk_ref *chunks;
-    const gcn10_inflate_tile *jobs;
-    size_t n;
-    uint8_t *dst;
-    pthread_mutex_t *mu;
-    pthread_cond_t *cv;
-    int *pending, *failed;
-};
-
-static void comp_job_run(void *arg)
-{
-    struct comp_job *j = arg;
-    int bad = 0;
-
-    for (size_t i = 0; i < j->n && !bad; i++) {
-        uint8_t *p = j->dst + j->jobs[i].in_off;
-        size_t left = j->chunks[i].nbytes;
-        uint64_t off = j->chunks[i].file_off;
-
-        while (left > 0) {
-            ssize_t got = pread(j->chunks[i].fd, p, left, (off_t)off);
-
-            if (got <= 0) {
-                bad = 1;
-                break;
-            }
-            p += got;
-            off += (uint64_t)got;
-            left -= (size_t)got;
-        }
-        memset(p, 0, 16);               /* the decoder's bit reader may look a few bytes ahead */
-    }
-    pthread_mutex_lock(j->mu);
-    if (bad)
-        *j->failed = 1;
-    if (--*j->pending == 0)
-        pthread_cond_broadcast(j->cv);
-    pthread_mutex_unlock(j->mu);
-    free(j);
-}
-
-/* Landcover window of the block -> w->d_block through the GPU decoder.  0 = issued on
- * s_kernel (statuses arrive with ev_inflate), 1 = this window needs the host reader,
- * -1 = error (logged). */
-static int inflate_block(struct worker *w, int xoff, int yoff, int W, int H, int block_id)
-{
-    struct run *r = w->run;
-    const struct gcn10_gpu_api *g = r->gpu;
-    struct gcn10_read_plan plan;
-    char err[1024] = "";
-    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
-    pthread_cond_t cv = PTHREAD_COND_INITIALIZER;
-    int pending = 0, failed = 0, rc;
-    size_t comp_bytes = 0;
-    double t0 = now_seconds();
-
-    rc = gcn10_raster_plan_window(w->esa, xoff, yoff, W, H, &plan, err, sizeof err);
-    if (rc > 0)
-        return 1;
-    if (rc < 0) {
-        wlog(w, "ERROR", true, "%s", err);
-        wlog(w, "ERROR", true, "esa load failed for block %d", block_id);
-        return -1;
-    }
-    rc = -1;
-    if (plan.n > w->jobs_cap) {
-        if (w->h_jobs) g->host_free(w->ctx, w->h_jobs);
-        if (w->d_jobs) g->free(w->ctx, w->d_jobs);
-        if (w->h_status) g->host_free(w->ctx, w->h_status);
-        if (w->d_status) g->free(w->ctx, w->d_status);
-        w->h_jobs = NULL;
-        w->d_jobs = NULL;
-        w->h_status = NULL;
-        w->d_status = NULL;
-        w->jobs_cap = 0;
-        if (g->host_alloc(w->ctx, plan.n * sizeof *w->h_jobs, (void **)&w->h_jobs) != 0 ||
-            g->malloc(w->ctx, plan.n * sizeof *w->d_jobs, (void **)&w->d_jobs) != 0 ||
-            g->host_alloc(w->ctx, plan.n * 4, (void **)&w->h_status) != 0 ||
-            g->malloc(w->ctx, plan.n * 4, (void **)&w->d_status) != 0)
-            goto gpu_fail;
-        w->jobs_cap = plan.n;
-    }
-    for (size_t i = 0; i < plan.n; i++) {
-        const struct gcn10_chunk_ref *c = &plan.chunks[i];
-        gcn10_inflate_tile *j = &w->h_jobs[i];
-
-        j->in_off = comp_bytes;
-        j->in_len = c->nbytes;
-        j->out_len = c->chunk_w * c->rows;
-        j->chunk_w = c->chunk_w;
-        j->src_x = c->src_x;
-        j->src_y = c->src_y;
-        j->copy_w = c->copy_w;
-        j->copy_h = c->copy_h;
-        j->reserved = 0;
-        j->dst_off = (uint64_t)c->dst_y * (uint64_t)W + c->dst_x;
-        comp_bytes += (((size_t)c->nbytes + 15) & ~(size_t)15) + 16;
-        w->h_status[i] = 0xffffffffu;
-    }
-    if (comp_bytes > w->h_comp_cap) {
-        size_t cap = comp_bytes + comp_bytes / 4 + 4096;
-
-        if (w->h_comp) g->host_free(w->ctx, w->h_comp);
-        if (w->d_comp) g->free(w->ctx, w->d_comp);
-        w->h_comp = NULL;
-        w->d_comp = NULL;
-        w->h_comp_cap = w->d_comp_cap = 0;
-        if (g->host_alloc(w->ctx, cap, (void **)&w->h_comp) != 0 ||
-            g->malloc(w->ctx, cap, (void **)&w->d_comp) != 0)
-            goto gpu_fail;
-        w->h_comp_cap = w->d_comp_cap = cap;
-    }
-    if (ensure_dev(w, (void **)&w->d_block, &w->block_cap, (size_t)W * (size_t)H) != 0)
-        goto out;
-    /* compressed bytes: a few dozen chunks per pool job */
-    for (size_t i = 0; i < plan.n; i += 32) {
-        struct comp_job *j = malloc(sizeof *j);
-        struct comp_job job = { plan.chunks + i, w->h_jobs + i, plan.n - i < 32 ? plan.n - i : 32, w->h_comp,
-                                &mu, &cv, &pending, &failed };
-
-        if (!j || !r->pool) {
-            struct comp_job *tmp = j ? j : malloc(sizeof *tmp);
-
-            if (!tmp) {
-                failed = 1;
-                break;
-            }
-            *tmp = job;
-            pthread_mutex_lock(&mu);
-            pending++;
-            pthread_mutex_unlock(&mu);
-            comp_job_run(tmp);
-            continue;
-        }
-        *j = job;
-        pthread_mutex_lock(&mu);
-        pending++;
-        pthread_mutex_unlock(&mu);
-        gcn10_pool_submit(r->pool, comp_job_run, j);
-    }
-    pthread_mutex_lock(&mu);
-    while (pending > 0)
-        pthread_cond_wait(&cv, &mu);
-    pthread_mutex_unlock(&mu);
-    w->t_read += now_seconds() - t0;
-    if (failed) {
-        wlog(w, "ERROR", true, "gdalrasterio error: cannot read the landcover tiles of the window %d,%d %dx%d",
-             xoff, yoff, W, H);
-        wlog(w, "ERROR", true, "esa load failed for block %d", block_id);
-        goto out;
-    }
-    if (plan.n == 0) {
-        if (g->memset(w->ctx, w->d_block, 0, (size_t)W * (size_t)H, w->s_kernel) != 0 ||
-            g->event_record(w->ctx, w->ev_inflate, w->s_kernel) != 0)
-            goto gpu_fail;
-        rc = 0;
-        goto out;
-    }
-    if (g->memcpy_h2d(w->ctx, w->d_comp, w->h_comp, comp_bytes, w->s_h2d) != 0 ||
-        g->memcpy_h2d(w->ctx, w->d_jobs, w->h_jobs, plan.n * sizeof *w->h_jobs, w->s_h2d) != 0 ||
-        g->memcpy_h2d(w->ctx, w->d_status, w->h_status, plan.n * 4, w->s_h2d) != 0 ||
-        g->event_record(w->ctx, w->ev_comp, w->s_h2d) != 0 ||
-        g->stream_wait_event(w->ctx, w->s_kernel, w->ev_comp) != 0 ||
-        (plan.covered < (uint64_t)W * (uint64_t)H &&
-         g->memset(w->ctx, w->d_block, 0, (size_t)W * (size_t)H, w->s_kernel) != 0) ||
-        g->inflate_tiles(w->ctx, w->d_comp, w->d_jobs, (int)plan.n, plan.max_chunk_bytes, w->d_block,
-                         (size_t)W, w->d_status, w->s_kernel) != 0 ||
-        g->memcpy_d2h(w->ctx, w->h_status, w->d_status, plan.n * 4, w->s_kernel) != 0 ||
-        g->event_record(w->ctx, w->ev_inflate, w->s_kernel) != 0)
-        goto gpu_fail;
-    w->n_inflate = plan.n;
-    rc = 0;
-    goto out;
-
-gpu_fail:
-    wlog(w, "ERROR", true, "gpu: %s", g->last_error());
-out:
-    /* the files may close: the compressed bytes are in pinned memory now */
-    gcn10_read_plan_free(&plan);
-    return rc;
 }
 
 /* returns 0 (done or skipped like the reference skips) or -1 for errors the
@@ -754,7 +484,7 @@ static int process_block(struct worker *w, int block_id)
     /* DEFLATE landcover (the ESA tiles): compressed chunks -> HBM -> decoded there */
     w->n_inflate = 0;
     if (r->gpu_inflate) {
-        int irc = inflate_block(w, xoff, yoff, W, H, block_id);
+        int irc = gcn10_inflate_block(w, xoff, yoff, W, H, block_id);
 
         if (irc < 0) {
             goto out;               /* logged; the block is skipped as after a failed load_raster */
