@@ -37,8 +37,8 @@ struct FusedJob {
     const uint8_t *hx;
     const int32_t *cj;
     const uint8_t *class_of;        // [36][256]; class_val [18][256] follows
-    uint8_t *tok;                   // [positions][kTileBytes] tokenised class tiles (F-A -> F-C)
-    unsigned long long *tok_start;  // [positions][kTile][4]   where their match tokens start
+    uint16_t *tok;                  // [positions][kTokStride] token stream of each tile position (F-A -> F-C)
+    uint32_t *n_tok;                // [positions] its length, end-of-block token included
     uint32_t hx_stride, hx_rows;
     uint32_t diag;                  // gcn10_gpu_set_option("fused_diag"): timing experiments
     uint32_t n_sel;                 // selected rasters, ascending
@@ -127,18 +127,22 @@ __device__ __forceinline__ int next_set(const unsigned long long (&m)[4], int x)
 //   row[x+1] = value of the length's extra bits | number of extra bits << 5
 //   row[x+2] = len - 3
 // and bit x of `start` is set.  Every mask of the tile must have been computed before.
-__device__ __forceinline__ void tokenise_row(uint8_t *tile, int t, const RowMasks &m, uint32_t *lit_hist,
-                                             uint32_t *dist_hist, unsigned long long (&start)[4])
+// Returns the number of tokens of the row.
+__device__ __forceinline__ uint32_t tokenise_row(uint8_t *tile, int t, const RowMasks &m, uint32_t *lit_hist,
+                                                 uint32_t *dist_hist, unsigned long long (&start)[4])
 {
     uint8_t *row = tile + t * kRowStride;
     int x = 0;
+    uint32_t n_tokens = 0;
     start[0] = start[1] = start[2] = start[3] = 0ull;
     while (x < kTile) {
         const int cand = next_candidate(m, x);
+        n_tokens += (uint32_t)(cand - x);
         for (; x < cand; x++)
             atomicAdd(&lit_hist[row[x]], 1u);
         if (x >= kTile)
             break;
+        n_tokens++;
         const int l1 = run_from(m.near_, x);
         const int l256 = run_from(m.far_, x);
         const bool far = l256 > l1;                 // tie: distance 1 (no extra bits)
@@ -159,7 +163,15 @@ __device__ __forceinline__ void tokenise_row(uint8_t *tile, int t, const RowMask
             x++;
         }
     }
+    return n_tokens;
 }
+
+// The token stream pass F-C reads, 16 bits per token, rows back to back:
+//   0x0000 | class                                  literal
+//   0x8000 | length code | extra value << 5 | far << 10   match (far: distance 256, else 1)
+//   0x4000                                          end of block
+constexpr uint32_t kTokMatch = 0x8000u, kTokEnd = 0x4000u;
+constexpr uint32_t kTokStride = kTileBytes + 64;    // tokens per tile position, worst case + the end token
 
 __device__ __forceinline__ uint32_t wave_sum64(uint32_t v)
 {
@@ -179,6 +191,7 @@ struct SharedFA {
             uint32_t n_c[256], w_c[256];                // pixels per class, sum of their Adler weights
             uint32_t H[kGroup][256];                    // literal counts by VALUE, kGroup rasters at a time
             uint32_t s1[GCN10_N_RASTERS], s2[GCN10_N_RASTERS];
+            uint32_t row_base[4];
         } a;
     };
 };
@@ -240,25 +253,42 @@ __global__ __launch_bounds__(kTile) void fused_stats_kernel(const FusedJob job)
         atomicAdd(&sh.a.w_c[cur], wsum);
     }
     unsigned long long start[4];
-    tokenise_row(sh.tile, t, m, sh.a.lit_hist, sh.a.dist_hist, start);
+    const uint32_t my_tokens = tokenise_row(sh.tile, t, m, sh.a.lit_hist, sh.a.dist_hist, start);
+    // rows back to back: where this row's tokens go
     {
-        unsigned long long *dst = job.tok_start + ((size_t)tix * kTile + t) * 4;
-        dst[0] = start[0];
-        dst[1] = start[1];
-        dst[2] = start[2];
-        dst[3] = start[3];
-    }
-    __syncthreads();
-    // the token tile -> workspace, a wave per row and step
-    {
-        uint32_t *dst = reinterpret_cast<uint32_t *>(job.tok + (size_t)tix * kTileBytes) + (t & 63);
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(sh.tile) + (t & 63);
-#pragma unroll 8
-        for (int i = 0; i < kTile / 4; i++) {
-            const int r = i * 4 + (t >> 6);
-            dst[r * (kTile / 4)] = src[r * (kRowStride / 4)];
+        uint32_t incl = my_tokens;
+        const int lane = t & 63;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, 64);
+            if (lane >= off)
+                incl += up;
+        }
+        if (lane == 63)
+            sh.a.row_base[t >> 6] = incl;
+        __syncthreads();
+        uint32_t at = incl - my_tokens;
+        for (int w = 0; w < (t >> 6); w++)
+            at += sh.a.row_base[w];
+        uint16_t *out = job.tok + (size_t)tix * kTokStride;
+        const uint8_t *row = sh.tile + t * kRowStride;
+        int x = 0;
+        while (x < kTile) {
+            const int p = next_set(start, x);
+            for (; x < p; x++)
+                out[at++] = (uint16_t)row[x];
+            if (x >= kTile)
+                break;
+            const uint32_t b0 = row[x], b1 = row[x + 1], b2 = row[x + 2];
+            out[at++] = (uint16_t)(kTokMatch | (b0 & 31u) | (b1 & 31u) << 5 | (b0 >> 7) << 10);
+            x += (int)b2 + 3;
+        }
+        if (t == kTile - 1) {
+            out[at] = (uint16_t)kTokEnd;
+            job.n_tok[tix] = at + 1u;
         }
     }
+    __syncthreads();
 
     // Adler-32 of every raster's tile: thread t = class t, s1 = 1 + sum n_c val, s2 = N + sum w_c val
     const uint32_t lits = sh.a.lit_hist[t];
@@ -310,71 +340,50 @@ __global__ __launch_bounds__(kTile) void fused_stats_kernel(const FusedJob job)
     }
 }
 
+// Inclusive prefix sum over the 64 lanes with DPP adds (no LDS traffic): three shifted adds of
+// the input give sums over 4 lanes, row_shr:4 / row_shr:8 complete the rows of 16, row_bcast:15
+// and row_bcast:31 carry the row totals on.
+__device__ __forceinline__ uint32_t wave_scan_dpp(uint32_t x)
+{
+    uint32_t r = x;
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);     // row_shr:1
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);     // row_shr:2
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x113, 0xf, 0xf, false);     // row_shr:3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x114, 0xf, 0xe, false);     // row_shr:4, lanes 4..15
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x118, 0xf, 0xc, false);     // row_shr:8, lanes 8..15
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
+    return r;
+}
+
+constexpr int kStageWords = 88;         // 64 tokens x 41 bits, starting anywhere in the first word
+
 struct SharedFC {
-    uint8_t tile[kTile * kRowStride];   // token tile
     union {
         struct {
             uint32_t cl[288][8];            // code | length << 16 of the group's rasters, by class / length symbol
-            uint32_t lenpack[288][kGroup / 2];  // the lengths alone, two rasters per dword (row measure)
+            uint32_t stage[4][kGroup][kStageWords];     // per wave: the bits of its 64 tokens, per raster
         } c;
-        uint8_t class_of[gcn10::kClassCodes * 256];     // stored fallback only, after the walk
+        uint8_t class_of[gcn10::kClassCodes * 256];     // stored fallback only, after the streams
     };
-    uint32_t wave_sum[kGroup][4];
+    uint32_t wave_tot[kGroup / 2][4];       // bits of each wave's tokens, two streams per word
+    uint32_t masks[2];
 };
 
-// A row's bits go straight into the stream's words in the arena: the words a row fills
-// completely are plain stores, its first and last (shared with the neighbouring rows, the
-// header or the trailer) are OR-ed into the zeroed slot.
-struct WordEmitter {
-    uint32_t *words;
-    uint32_t wpos;
-    unsigned long long acc;
-    uint32_t nacc;
-    bool first;
-    bool dry;
-    __device__ __forceinline__ void init(uint32_t *w, uint32_t start_bit)
-    {
-        dry = false;
-        words = w;
-        wpos = start_bit >> 5;
-        nacc = start_bit & 31u;
-        acc = 0ull;
-        first = true;
-    }
-    __device__ __forceinline__ void put(uint32_t value, uint32_t nbits)
-    {
-        acc |= (unsigned long long)value << nacc;
-        nacc += nbits;
-        if (nacc >= 32u) {
-            if (dry)
-                ;
-            else if (first)
-                atomicOr(&words[wpos], (uint32_t)acc);
-            else
-                words[wpos] = (uint32_t)acc;
-            first = false;
-            wpos++;
-            acc >>= 32;
-            nacc -= 32u;
-        }
-    }
-    __device__ __forceinline__ void finish()
-    {
-        if (nacc > 0u && !dry)
-            atomicOr(&words[wpos], (uint32_t)acc & (0xffffffffu >> (32u - nacc)));
-    }
-};
-
-// pass F-C: one workgroup per (tile position, group of kGroup rasters).  The token tile is
-// loaded once; one walk over each row measures it for all rasters of the group (packed
-// 16-bit sums), a prefix sum places the rows, and ONE more walk emits the row for all
-// rasters of the group at once: per token one LDS read of the group's codes, kGroup bit
-// accumulators in registers, words written straight to the arena (no stream image in LDS).
+// pass F-C: one workgroup per (tile position, group of kGroup rasters), token-parallel.
+// Every thread takes one token of the position's stream per trip, looks up the group's codes
+// for it (one LDS read), a prefix sum over the workgroup gives its bit position in each of
+// the kGroup streams, the bits are OR-ed into a per-wave staging area in LDS and go to the
+// arena as whole words (the first and last word of a wave's span are OR-ed into the zeroed
+// slot, the words in between are plain coalesced stores).  No row walk, no divergence: the
+// work is the number of tokens, whatever their distribution over the rows.
 __global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     SharedFC &sh = *reinterpret_cast<SharedFC *>(smem);
     const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);        // wave-uniform: selects on it stay scalar
     const uint32_t tiles = job.t.across * job.t.down;
     const uint32_t tix = blockIdx.x;
     const uint32_t ty = tix / job.t.across, tx = tix - ty * job.t.across;
@@ -383,7 +392,7 @@ __global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
     const uint8_t *class_val = job.class_of + gcn10::kClassCodes * 256;
 
     // which rasters of the group have a slot, and which of those are stored
-    uint32_t live = 0, stored_mask = 0;
+    uint32_t live, stored_mask;
     {
         int mine = 0, st = 0;
         if ((uint32_t)t < nj) {
@@ -394,59 +403,35 @@ __global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
         live = (uint32_t)__ballot(mine);            // threads t < nj are all in wave 0: its ballots are the
         stored_mask = (uint32_t)__ballot(st);       // masks, the other waves get them through LDS
         if (t == 0) {
-            sh.wave_sum[0][0] = live;
-            sh.wave_sum[0][1] = stored_mask;
+            sh.masks[0] = live;
+            sh.masks[1] = stored_mask;
         }
         __syncthreads();
-        live = sh.wave_sum[0][0];
-        stored_mask = sh.wave_sum[0][1];
-        __syncthreads();
+        live = sh.masks[0];
+        stored_mask = sh.masks[1];
         if (live == 0)
             return;
     }
     const uint32_t coded = live & ~stored_mask;     // rasters that get a Huffman stream
 
-    // token tile and this row's match starts
-    {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(job.tok + (size_t)tix * kTileBytes) + (t & 63);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(sh.tile) + (t & 63);
-        uint32_t v[kTile / 4];
-#pragma unroll
-        for (int i = 0; i < kTile / 4; i++)
-            v[i] = src[(i * 4 + (t >> 6)) * (kTile / 4)];
-#pragma unroll
-        for (int i = 0; i < kTile / 4; i++)
-            dst[(i * 4 + (t >> 6)) * (kRowStride / 4)] = v[i];
-    }
-    unsigned long long start[4];
-    {
-        const unsigned long long *src = job.tok_start + ((size_t)tix * kTile + t) * 4;
-        start[0] = src[0];
-        start[1] = src[1];
-        start[2] = src[2];
-        start[3] = src[3];
-    }
     // codes of the group's rasters by class (a literal of class c is the symbol val(c)), the
-    // zeroed slots with their block headers, and per raster what is the same for every row
+    // zeroed slots with their block headers, and per raster what is the same for every token
     uint32_t *words[kGroup];
-    uint32_t header_bits[kGroup], dcode0[kGroup], dlen0[kGroup], dcode1[kGroup], dlen1[kGroup];
-    uint32_t dist_pack[2][kGroup / 2] = {};
+    uint32_t base[kGroup], dcode0[kGroup], dlen0[kGroup], dcode1[kGroup], dlen1[kGroup];
 #pragma unroll
     for (int k = 0; k < kGroup; k++) {
         words[k] = nullptr;
-        header_bits[k] = dcode0[k] = dlen0[k] = dcode1[k] = dlen1[k] = 0;
+        base[k] = dcode0[k] = dlen0[k] = dcode1[k] = dlen1[k] = 0;
         if (!((coded >> k) & 1u))
             continue;
         const uint32_t j = j0 + k;
         const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)j * tiles + tix) * kBookBytes);
         words[k] = reinterpret_cast<uint32_t *>(job.t.arena + b->slot);
-        header_bits[k] = b->header_bits;
+        base[k] = b->header_bits;
         dcode0[k] = b->dist_code[0];
         dlen0[k] = b->dist_len[0];
         dcode1[k] = (uint32_t)b->dist_code[1] | 63u << b->dist_len[1];      // + 6 extra bits: 256 - 193
         dlen1[k] = (uint32_t)b->dist_len[1] + 6u;
-        dist_pack[0][k / 2] |= dlen0[k] << (16 * (k & 1));
-        dist_pack[1][k / 2] |= dlen1[k] << (16 * (k & 1));
         const uint32_t n_words = (b->stream_bytes + 3u) / 4u;
         for (uint32_t i = t; i < n_words; i += kTile)
             words[k][i] = i < 64u ? b->header[i] : 0u;
@@ -455,117 +440,86 @@ __global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
             sh.c.cl[i][k] = (uint32_t)b->lit_code[sym] | (uint32_t)b->lit_len[sym] << 16;
         }
     }
-    __syncthreads();
-    for (int i = t; i < 288; i += kTile) {
-#pragma unroll
-        for (int k = 0; k < kGroup; k += 2) {
-            const uint32_t lo = ((coded >> k) & 1u) ? sh.c.cl[i][k] >> 16 : 0u;
-            const uint32_t hi = ((coded >> (k + 1)) & 1u) ? sh.c.cl[i][k + 1] >> 16 : 0u;
-            sh.c.lenpack[i][k / 2] = lo | hi << 16;
-        }
-    }
-    __threadfence();                                // the zeroed slots are in place before any row ORs into them
+    for (int i = t; i < 4 * kGroup * kStageWords; i += kTile)
+        (&sh.c.stage[0][0][0])[i] = 0u;
+    __threadfence();                                // the zeroed slots are in place before anything is OR-ed into them
     __syncthreads();
 
-    if (coded) {
-        const uint8_t *row = sh.tile + t * kRowStride;
-        // bits of row t in every raster of the group
-        uint32_t acc[kGroup / 2] = {};
-        {
-            int x = (job.diag & 4u) ? kTile : 0;
-            while (x < kTile) {
-                const int p = next_set(start, x);
-                for (; x < p; x++) {
-                    const uint32_t *lp = sh.c.lenpack[row[x]];
-#pragma unroll
-                    for (int k = 0; k < kGroup / 2; k++)
-                        acc[k] += lp[k];
-                }
-                if (x >= kTile)
-                    break;
-                const uint32_t b0 = row[x], b1 = row[x + 1], b2 = row[x + 2];
-                const uint32_t *lp = sh.c.lenpack[257u + (b0 & 31u)];
-                const uint32_t far = b0 >> 7;
-                const uint32_t common = (b1 >> 5) * 0x00010001u;
-#pragma unroll
-                for (int k = 0; k < kGroup / 2; k++)
-                    acc[k] += lp[k] + common + (far ? dist_pack[1][k] : dist_pack[0][k]);
-                x += (int)b2 + 3;
-            }
-        }
-        // exclusive prefix over rows, all rasters of the group at once
-        uint32_t first_bit[kGroup];
-        {
-            uint32_t v[kGroup];
-            const int lane = t & 63;
+    if (coded && !(job.diag & 2u)) {
+        const uint16_t *tok = job.tok + (size_t)tix * kTokStride;
+        const uint32_t n_tok = job.n_tok[tix];
+        for (uint32_t i0 = 0; i0 < n_tok; i0 += kTile) {
+            const uint32_t i = i0 + (uint32_t)t;
+            const bool have = i < n_tok;
+            const uint32_t tk = have ? tok[i] : 0u;
+            const bool is_match = (tk & kTokMatch) != 0;
+            const uint32_t sym = is_match ? 257u + (tk & 31u) : (tk & kTokEnd) ? 256u : (tk & 255u);
+            const uint32_t lc = tk & 31u;
+            const uint32_t ne = !is_match || lc < 8u || lc == 28u ? 0u : (lc - 4u) >> 2;
+            const uint32_t ev = is_match ? (tk >> 5) & 31u : 0u;
+            const bool far = ((tk >> 10) & 1u) != 0;
+            const u32x4 c03 = *reinterpret_cast<const u32x4 *>(&sh.c.cl[sym][0]);
+            const u32x4 c47 = *reinterpret_cast<const u32x4 *>(&sh.c.cl[sym][4]);
+            // the token's bits in every stream of the group: at most 15 + 5 + 15 + 6 = 41
+            uint32_t lo[kGroup], hi[kGroup], n[kGroup];
 #pragma unroll
             for (int k = 0; k < kGroup; k++) {
-                const uint32_t mine = (acc[k / 2] >> (16 * (k & 1))) & 0xffffu;
-                uint32_t s = mine;
+                const uint32_t c = k < 4 ? c03[k] : c47[k - 4];
+                const uint32_t l = c >> 16;
+                const uint32_t nb = l + ne;                         // <= 20
+                const uint32_t d = is_match ? (far ? dcode1[k] : dcode0[k]) : 0u;
+                const uint32_t dl = is_match ? (far ? dlen1[k] : dlen0[k]) : 0u;
+                lo[k] = (c & 0xffffu) | ev << l | d << nb;
+                hi[k] = (d >> 1) >> (31u - nb);
+                n[k] = have && ((coded >> k) & 1u) ? nb + dl : 0u;
+            }
+            // prefix sums over the wave, two streams per register (a wave's total is < 2^16)
+            uint32_t excl[kGroup];
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const uint32_t up = __shfl_up(s, off, 64);
-                    if (lane >= off)
-                        s += up;
-                }
+            for (int k = 0; k < kGroup; k += 2) {
+                const uint32_t mine = n[k] | n[k + 1] << 16;
+                const uint32_t incl = wave_scan_dpp(mine);
+                const uint32_t ex = incl - mine;
+                excl[k] = ex & 0xffffu;
+                excl[k + 1] = ex >> 16;
                 if (lane == 63)
-                    sh.wave_sum[k][t >> 6] = s;
-                v[k] = s - mine;
+                    sh.wave_tot[k / 2][wave] = incl;
             }
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < kGroup; k++) {
-                uint32_t base = 0;
-                for (int w = 0; w < (t >> 6); w++)
-                    base += sh.wave_sum[k][w];
-                first_bit[k] = v[k] + base;
-            }
-        }
-        // the row, for every raster of the group in one walk
-        WordEmitter em[kGroup];
-#pragma unroll
-        for (int k = 0; k < kGroup; k++) {
-            em[k].init(words[k], header_bits[k] + first_bit[k]);
-            em[k].dry = (job.diag & 1u) != 0;
-        }
-        int x = (job.diag & 2u) ? kTile : 0;
-        while (x < kTile) {
-            const int p = next_set(start, x);
-            for (; x < p; x++) {
-                const uint32_t *cl = sh.c.cl[row[x]];
-#pragma unroll
-                for (int k = 0; k < kGroup; k++) {
-                    if ((coded >> k) & 1u) {
-                        const uint32_t c = cl[k];
-                        em[k].put(c & 0xffffu, c >> 16);
-                    }
+                if (!((coded >> k) & 1u))
+                    continue;
+                const int h = 16 * (k & 1);
+                const uint32_t t0 = (sh.wave_tot[k / 2][0] >> h) & 0xffffu, t1 = (sh.wave_tot[k / 2][1] >> h) & 0xffffu,
+                               t2 = (sh.wave_tot[k / 2][2] >> h) & 0xffffu, t3 = (sh.wave_tot[k / 2][3] >> h) & 0xffffu;
+                const uint32_t before = wave == 0 ? 0u : wave == 1 ? t0 : wave == 2 ? t0 + t1 : t0 + t1 + t2;
+                const uint32_t mine = wave == 0 ? t0 : wave == 1 ? t1 : wave == 2 ? t2 : t3;
+                const uint32_t first = base[k] + before;            // this wave's first bit in the stream
+                const uint32_t word0 = first >> 5;
+                uint32_t *stage = sh.c.stage[wave][k];
+                {
+                    // 41 bits shifted by up to 31: three words, OR-ed unconditionally (absent tokens are zeros)
+                    const uint32_t rel = (first & 31u) + excl[k];
+                    const uint32_t w = rel >> 5, sft = rel & 31u;
+                    const uint32_t l32 = n[k] ? lo[k] : 0u, h32 = n[k] ? hi[k] : 0u;
+                    atomicOr(&stage[w], l32 << sft);
+                    atomicOr(&stage[w + 1], (l32 >> 1) >> (31u - sft) | h32 << sft);
+                    atomicOr(&stage[w + 2], (h32 >> 1) >> (31u - sft));
                 }
-            }
-            if (x >= kTile)
-                break;
-            const uint32_t b0 = row[x], b1 = row[x + 1], b2 = row[x + 2];
-            const uint32_t *cl = sh.c.cl[257u + (b0 & 31u)];
-            const bool far = (b0 >> 7) != 0;
-#pragma unroll
-            for (int k = 0; k < kGroup; k++) {
-                if ((coded >> k) & 1u) {
-                    const uint32_t c = cl[k];
-                    const uint32_t l = c >> 16;
-                    em[k].put((c & 0xffffu) | (b1 & 31u) << l, l + (b1 >> 5));      // <= 15 + 5 bits
-                    em[k].put(far ? dcode1[k] : dcode0[k], far ? dlen1[k] : dlen0[k]);  // <= 15 + 6 bits
+                // (one wave: the LDS atomics above are complete before the reads below issue)
+                const uint32_t n_words = ((first & 31u) + mine + 31u) >> 5;
+                for (uint32_t w = (uint32_t)lane; w < n_words; w += 64u) {
+                    const uint32_t val = stage[w];
+                    stage[w] = 0u;
+                    if (w == 0u || w == n_words - 1u)
+                        atomicOr(&words[k][word0 + w], val);
+                    else
+                        words[k][word0 + w] = val;
                 }
+                base[k] += t0 + t1 + t2 + t3;
             }
-            x += (int)b2 + 3;
-        }
-#pragma unroll
-        for (int k = 0; k < kGroup; k++) {
-            if ((coded >> k) & 1u) {
-                if (t == kTile - 1) {
-                    const uint32_t c = sh.c.cl[256][k];
-                    em[k].put(c & 0xffffu, c >> 16);                               // end of block
-                }
-                em[k].finish();
-            }
+            __syncthreads();                        // wave_tot is rewritten in the next trip
         }
     }
     // trailers: the Adler-32 of the raster's tile, big endian, after the last (padded) byte
@@ -585,7 +539,7 @@ __global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
         return;
 
     // stored fallback (incompressible tiles): the raster's bytes are val(class), two blocks of
-    // 32768 bytes; the classes are formed again from landcover + soil (the tile in LDS holds tokens)
+    // 32768 bytes; the classes are formed again from landcover + soil
     __syncthreads();
     for (int i = t; i < gcn10::kClassCodes * 256 / 4; i += kTile)
         reinterpret_cast<uint32_t *>(sh.class_of)[i] = reinterpret_cast<const uint32_t *>(job.class_of)[i];
@@ -687,17 +641,18 @@ int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W,
 
     // workspace: statistics + code books per (raster, tile), token tiles + match starts per position
     const size_t stats_bytes = ((size_t)nblocks * ((size_t)kHistWords * 4 + (size_t)kBookBytes) + 255) & ~(size_t)255;
-    const size_t need = stats_bytes + (size_t)positions * ((size_t)kTileBytes + (size_t)kTile * 32);
+    const size_t tok_bytes = (size_t)positions * kTokStride * sizeof(uint16_t);
+    const size_t need = stats_bytes + tok_bytes + (size_t)positions * sizeof(uint32_t);
     rc = gcn10::deflate_workspace(ctx, need);
     if (rc)
         return rc;
     job.t.hist = reinterpret_cast<uint32_t *>(ctx->deflate_ws);
     job.t.books = reinterpret_cast<uint8_t *>(ctx->deflate_ws) + (size_t)nblocks * kHistWords * 4;
-    job.tok = reinterpret_cast<uint8_t *>(ctx->deflate_ws) + stats_bytes;
-    job.tok_start = reinterpret_cast<unsigned long long *>(job.tok + (size_t)positions * kTileBytes);
+    job.tok = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(ctx->deflate_ws) + stats_bytes);
+    job.n_tok = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(ctx->deflate_ws) + stats_bytes + tok_bytes);
 
     static_assert(sizeof(SharedFA) <= 80 * 1024, "two fused statistics workgroups per CU");
-    static_assert(sizeof(SharedFC) <= 80 * 1024, "two fused emit workgroups per CU");
+    static_assert(sizeof(SharedFC) <= 20 * 1024, "eight fused emit workgroups per CU");
     if (!ctx->fused_ready) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_stats_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SharedFA)));

@@ -58,8 +58,8 @@ struct gcn10_gpu_ctx {
     uint8_t *d_class_of = nullptr;  // [36][256] pixel class of (soil code, landcover), then [18][256] values
     int n_classes = 0;              // 0: not available (set_tables not called, or > 256 classes)
     int deflate_wave_codes = 1;     // pass B of the tile encoder: 1 = one wave per tile, 0 = one thread
-    int fused_diag = 0;             // timing experiments only (streams become invalid): 1 no word stores,
-                                    // 2 no emit walk, 4 no measure walk
+    int fused_diag = 0;             // timing experiments only (streams become invalid): 2 = pass F-C
+                                    // without its token trips (set-up cost alone)
     bool fused_ready = false;
     bool codes_ready = false;       // LDS attribute of the per-thread code construction set
     bool deflate_ready = false;     // LDS attributes of the tile encoder set on this device
