@@ -228,29 +228,22 @@ __global__ __launch_bounds__(kTile) void fused_stats_kernel(const FusedJob job)
     row_masks(sh.tile, t, m);
     __syncthreads();                                // every mask is built: rows may be rewritten
 
-    // pixels and Adler weights per class, run by run along row t (weight of byte i: 65536 - i)
+    // pixels and Adler weights per class, run by run along row t (weight of byte i of the tile:
+    // 65536 - i).  Runs end where the "equals its left neighbour" mask has a zero, so a row costs
+    // as many steps as it has runs, not 256.
     {
         const uint8_t *row = sh.tile + t * kRowStride;
-        uint32_t cur = row[0], n = 1;
-        uint32_t wgt = (uint32_t)kTileBytes - (uint32_t)t * kTile;
-        uint32_t wsum = wgt;
-        for (int x = 1; x < kTile; x++) {
-            const uint32_t c = row[x];
-            wgt--;
-            if (c == cur) {
-                n++;
-                wsum += wgt;
-            }
-            else {
-                atomicAdd(&sh.a.n_c[cur], n);
-                atomicAdd(&sh.a.w_c[cur], wsum);
-                cur = c;
-                n = 1;
-                wsum = wgt;
-            }
+        unsigned long long brk[4] = { ~m.near_[0] | 1ull, ~m.near_[1], ~m.near_[2], ~m.near_[3] };
+        const uint32_t w0 = (uint32_t)kTileBytes - (uint32_t)t * kTile;        // weight of the row's first byte
+        int x0 = 0;
+        while (x0 < kTile) {
+            const int x1 = next_set(brk, x0 + 1);           // the next run's start, or the row's end
+            const uint32_t n = (uint32_t)(x1 - x0);
+            const uint32_t c = row[x0];
+            atomicAdd(&sh.a.n_c[c], n);
+            atomicAdd(&sh.a.w_c[c], n * w0 - ((n * (uint32_t)(x0 + x1 - 1)) >> 1));
+            x0 = x1;
         }
-        atomicAdd(&sh.a.n_c[cur], n);
-        atomicAdd(&sh.a.w_c[cur], wsum);
     }
     unsigned long long start[4];
     const uint32_t my_tokens = tokenise_row(sh.tile, t, m, sh.a.lit_hist, sh.a.dist_hist, start);

@@ -284,15 +284,39 @@ static void free_strip_buffers(struct worker *w)
         b->h_esa = b->d_esa = NULL;
     }
     w->buf_px = 0;
+    w->buf_tiles = 0;
 }
 
-/* strip buffers sized for blocks W wide: 2 x (1 + 18) pinned + the same in HBM */
+/* Rows per strip for blocks W wide: whole tile rows, 4..8 of them, such that the tile positions of
+ * a strip fill the GPU's workgroup slots (two of the encoder's statistics workgroups fit a CU) in
+ * whole rounds: 141 positions across x 7 = 987 of 2 x 512 slots on an MI355X, where 4 rows would
+ * leave the second round 90 % empty. */
+static int pick_strip_rows(int W, int n_cus)
+{
+    long across = (W + TILE - 1) / TILE, slots = 2L * (n_cus > 0 ? n_cus : 256);
+    int best = 4;
+    double best_fill = 0.0;
+
+    for (int d = 4; d <= 8; d++) {
+        long pos = across * d, rounds = (pos + slots - 1) / slots;
+        double fill = (double)pos / (double)(rounds * slots);
+
+        if (fill > best_fill + 1e-9) {
+            best_fill = fill;
+            best = d;
+        }
+    }
+    return best * TILE;
+}
+
+/* strip buffers sized for blocks W wide: nbuf x (1 + 18) pinned + the same in HBM */
 static int ensure_strip_buffers(struct worker *w, int W)
 {
     const struct gcn10_gpu_api *g = w->run->gpu;
-    size_t px = (size_t)W * (size_t)w->run->strip_rows;
+    size_t px = (size_t)W * (size_t)w->strip_rows;
+    size_t n_tiles = (size_t)((W + TILE - 1) / TILE) * (size_t)(w->strip_rows / TILE);
 
-    if (px <= w->buf_px)
+    if (px <= w->buf_px && n_tiles <= w->buf_tiles)
         return 0;
     free_strip_buffers(w);
     for (int i = 0; i < w->run->nbuf; i++) {
@@ -307,9 +331,9 @@ static int ensure_strip_buffers(struct worker *w, int W)
                 GPU_TRY(w, g->malloc(w->ctx, px, (void **)&b->d_out[k]));
         }
         if (w->run->gpu_deflate) {
-            size_t tiles = (size_t)((W + TILE - 1) / TILE) * (size_t)(w->run->strip_rows / TILE);
+            size_t tiles = n_tiles;
 
-            b->arena_cap = g->deflate_arena_bound(W, w->run->strip_rows, GCN10_N_RASTERS);
+            b->arena_cap = g->deflate_arena_bound(W, w->strip_rows, GCN10_N_RASTERS);
             GPU_TRY(w, g->malloc(w->ctx, b->arena_cap, (void **)&b->d_arena));
             b->h_arena_cap = b->arena_cap / 8 > ((size_t)32 << 20) ? b->arena_cap / 8 : ((size_t)32 << 20);
             if (getenv("GCN10_PINNED_ARENA_BYTES"))        /* tests: force the spill path */
@@ -332,6 +356,7 @@ static int ensure_strip_buffers(struct worker *w, int W)
         }
     }
     w->buf_px = px;
+    w->buf_tiles = n_tiles;
     return 0;
 }
 
@@ -461,6 +486,7 @@ static int process_block(struct worker *w, int block_id)
     t_mark = now_seconds();
 
     /* device side of the block */
+    w->strip_rows = r->strip_rows > 0 ? r->strip_rows : pick_strip_rows(W, w->n_cus);
     if (ensure_strip_buffers(w, W) != 0 ||
         ensure_dev(w, (void **)&w->d_coarse, &w->coarse_cap, (size_t)hsx * hsy) != 0 ||
         ensure_dev(w, (void **)&w->d_ci, &w->ci_cap, (size_t)W * 4) != 0 ||
@@ -494,11 +520,11 @@ static int process_block(struct worker *w, int block_id)
 
     /* strips: rows are multiples of 256 (whole GeoTIFF tile rows) and of 16
      * (16-byte aligned strip starts for any W) */
-    n_strips = (H + r->strip_rows - 1) / r->strip_rows;
+    n_strips = (H + w->strip_rows - 1) / w->strip_rows;
     for (int s = 0; s < n_strips; s++) {
         struct strip_buf *b = &w->buf[s % r->nbuf];
-        int y0 = s * r->strip_rows;
-        int rows = H - y0 < r->strip_rows ? H - y0 : r->strip_rows;
+        int y0 = s * w->strip_rows;
+        int rows = H - y0 < w->strip_rows ? H - y0 : w->strip_rows;
         size_t px = (size_t)W * (size_t)rows;
         uint8_t *outs[GCN10_N_RASTERS];
 
@@ -779,6 +805,13 @@ static int worker_setup(struct worker *w)
         wlog(w, "ERROR", true, "gpu %d: %s", w->index % r->n_devices, g->last_error());
         return -1;
     }
+    {
+        char name[128];
+        size_t hbm = 0;
+        int cus = g->device_info(w->ctx, name, sizeof name, &hbm);
+
+        w->n_cus = cus > 0 ? cus : 256;
+    }
     GPU_TRY(w, g->set_tables(w->ctx, &r->tables[0][0][0], 9));
     w->fused = r->fused && g->deflate_fused_available(w->ctx) == 1;
     if (r->fused && !w->fused)
@@ -907,8 +940,7 @@ int gcn10_run(const gcn10_run_options *opt)
         return 1;
     }
     r->null_sink = sink && strcmp(sink, "null") == 0;
-    r->strip_rows = r->cfg.strip_rows > 0 ? r->cfg.strip_rows : DEFAULT_STRIP_ROWS;
-    r->strip_rows = (r->strip_rows + TILE - 1) / TILE * TILE;
+    r->strip_rows = r->cfg.strip_rows > 0 ? (r->cfg.strip_rows + TILE - 1) / TILE * TILE : 0;
     r->deflate_level = r->cfg.deflate_level;
     r->gpu_deflate = r->cfg.gpu_deflate != 0;
     r->fused = r->cfg.gpu_deflate == 2;

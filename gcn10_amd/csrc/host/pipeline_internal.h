@@ -12,7 +12,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-enum { TILE = 256, MAX_NBUF = 4, DEFAULT_NBUF = 3, DEFAULT_STRIP_ROWS = 1024 };
+enum { TILE = 256, MAX_NBUF = 4, DEFAULT_NBUF = 3 };
 
 struct run;
 
@@ -51,6 +51,9 @@ struct worker {
     gcn10_stream_t s_h2d, s_kernel, s_d2h;
     gcn10_raster *esa, *soil;
     size_t buf_px;                          /* capacity of one strip buffer, pixels */
+    size_t buf_tiles;                       /* ... and in 256x256 tiles */
+    int strip_rows;                         /* rows per strip of the current block */
+    int n_cus;                              /* compute units of this worker's GPU */
     struct strip_buf buf[MAX_NBUF];         /* the first run->nbuf are in use */
     uint8_t *d_coarse;
     size_t coarse_cap;
@@ -87,7 +90,7 @@ struct run {
     gcn10_pool *pool;
     atomic_int next_block;
     atomic_int fatal;                       /* a worker hit an MPI_Abort-class error */
-    int strip_rows;
+    int strip_rows;                         /* "strip_rows" of the config, 0 = chosen per block width */
     int nbuf;                               /* strip buffer sets per worker (GCN10_STRIP_BUFFERS, 2..4) */
     int deflate_level;
     bool null_sink;                         /* GCN10_SINK=null: no compression, no files */

@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--size", type=int, default=36000)
     ap.add_argument("--blocks", type=int, default=2)
     ap.add_argument("--workdir", default="/tmp/gcn10_pipeline_bench")
-    ap.add_argument("--strip-rows", type=int, default=1024)
+    ap.add_argument("--strip-rows", type=int, default=0, help="0 = the program's choice")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--modes", default="null,files")
     ap.add_argument("--pattern", default="patches")
