@@ -52,7 +52,20 @@ enum {
     kErrCode = 5,           // a bit pattern that is no code of the current block
     kErrDistance = 6,       // distance reaches before the start of the output
     kErrInput = 7,          // ran past the end of the compressed bytes
+    kErrWindow = 8,         // the descriptor's window does not lie inside its chunk
 };
+
+// the wanted window must lie inside the decoded chunk (and the chunk inside its slot)
+__device__ __forceinline__ bool window_ok(uint32_t out_len, uint32_t chunk_w, uint32_t src_x, uint32_t src_y,
+                                          uint32_t copy_w, uint32_t copy_h, uint32_t slot_bytes)
+{
+    if (copy_w == 0 || copy_h == 0)
+        return true;
+    if (chunk_w == 0 || out_len > slot_bytes || src_x > chunk_w || copy_w > chunk_w - src_x)
+        return false;
+    const unsigned long long last = (unsigned long long)(src_y + copy_h - 1u) * chunk_w + src_x + copy_w;
+    return (unsigned long long)src_y + copy_h <= 0xffffffffull && last <= out_len;
+}
 
 struct Code {               // canonical code, by length
     uint16_t count[16];
@@ -632,6 +645,8 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *comp, const 
     }
     if (!err && reader_byte_pos(r) > in_len + 4u)
         err = kErrInput;
+    if (!err && !window_ok(tin.out_len, tin.chunk_w, tin.src_x, tin.src_y, tin.copy_w, tin.copy_h, slot_bytes))
+        err = kErrWindow;
 
     // what is still in the window, then zeros up to the tile's size (as a short stream reads on the host)
     {
@@ -651,6 +666,8 @@ __global__ __launch_bounds__(256) void untile_kernel(const TileIn *tiles, const 
 {
     typedef uint32_t u32_u __attribute__((aligned(1)));
     const TileIn tin = tiles[blockIdx.x];
+    if (!window_ok(tin.out_len, tin.chunk_w, tin.src_x, tin.src_y, tin.copy_w, tin.copy_h, slot_bytes))
+        return;                                 // inflate_kernel has set the status
     const uint8_t *src = scratch + (size_t)blockIdx.x * slot_bytes + (size_t)tin.src_y * tin.chunk_w + tin.src_x;
     uint8_t *out = dst + tin.dst_off;
     const uint32_t w4 = tin.copy_w / 4u;

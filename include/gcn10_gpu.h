@@ -222,7 +222,7 @@ typedef struct gcn10_inflate_tile {
 enum {
     GCN10_INFLATE_E_HEADER = 1, GCN10_INFLATE_E_BLOCK_TYPE = 2, GCN10_INFLATE_E_STORED = 3,
     GCN10_INFLATE_E_LENGTHS = 4, GCN10_INFLATE_E_CODE = 5, GCN10_INFLATE_E_DISTANCE = 6,
-    GCN10_INFLATE_E_INPUT = 7
+    GCN10_INFLATE_E_INPUT = 7, GCN10_INFLATE_E_WINDOW = 8
 };
 int gcn10_gpu_inflate_tiles(gcn10_gpu_ctx *ctx, const uint8_t *comp_dev,
                             const gcn10_inflate_tile *tiles_dev, int n_tiles, uint32_t chunk_bytes,

@@ -193,6 +193,16 @@ def test_malformed_streams_report_a_status(engine):
     assert st == 6
 
 
+def test_window_outside_its_chunk_is_refused(engine):
+    raw = _data("classes", 100 * 30, 4)
+    st = _compress(raw)
+    for win in [(90, 0, 20, 5, 0, 0), (0, 28, 10, 5, 0, 0), (101, 0, 1, 1, 0, 0)]:
+        out, status = engine.inflate_tiles([st], 100, [30], [win], (40, 40))
+        assert int(status[0]) == 8 and not out.any(), win
+    out, status = engine.inflate_tiles([st], 100, [30], [(90, 25, 10, 5, 3, 2)], (40, 40))
+    assert int(status[0]) == 0 and np.array_equal(out[2:7, 3:13], raw.reshape(30, 100)[25:, 90:])
+
+
 def test_argument_errors(engine):
     with pytest.raises(gpu.Gcn10GpuError):
         engine._chk(gpu.lib().gcn10_gpu_inflate_tiles(engine._ctx, None, None, 3, 100, None, 100, None, None), "x")
