@@ -8,16 +8,19 @@
 // HBM: a DEFLATE stream is serial, a block's ~1300 tiles are not, so one wavefront decodes
 // one tile and a launch decodes them all.
 //
-// One wavefront per stream (RFC 1950 wrapper, RFC 1951 stored / fixed / dynamic blocks):
-//   input    each lane holds one dword of a 256-byte piece of the stream (plus the next
-//            piece, already in flight); the bit reader takes dwords with v_readlane at a
+// One workgroup of two wavefronts per stream (RFC 1950 wrapper, RFC 1951 stored / fixed /
+// dynamic blocks): the DECODER wave turns bits into tokens (literals, match, stored run), the
+// COPIER wave carries tokens out on the window; they swap halves of a 2 x 32-token ring at a
+// barrier, so the serial bit decode -- the bound of the whole thing -- never waits for a copy.
+//   input    each decoder lane holds one dword of a 256-byte piece of the stream (plus the
+//            next piece, already in flight); the bit reader takes dwords with v_readlane at a
 //            wave-uniform index, so the decode state lives in scalar registers
 //   tables   canonical codes are sorted by (length, symbol) with ballots; the 10-bit
 //            (literal/length) and 9-bit (distance) lookup tables are filled entry-parallel,
 //            16 resp. 8 entries per lane; longer codes take a bit-serial canonical walk
 //   window   the last 32 KiB of output live in LDS (reads after writes are ordered there);
-//            a match is copied by all lanes, 64 bytes per step, also when it overlaps itself;
-//            every 16 KiB the finished half goes to HBM as 16 B per lane
+//            a match is copied by all copier lanes, 64 bytes per step, also when it overlaps
+//            itself; every 16 KiB the finished half goes to HBM as 16 B per lane
 //   output   each tile decodes into its own linear slot; untile_kernel then copies the
 //            wanted window of every tile into the row-major landcover block.
 // Malformed streams end with a status code, never with a wild access or an endless loop
@@ -40,6 +43,7 @@ namespace {
 constexpr int kWindow = 32768;
 constexpr int kWindowMask = kWindow - 1;
 constexpr int kFlush = 16384;
+constexpr int kBatch = 32;              // tokens per hand-over from the decoder to the copier
 constexpr int kLitRoot = 10;
 constexpr int kDistRoot = 9;
 
@@ -81,6 +85,12 @@ struct Shared {
     uint16_t dist_sorted[32];
     uint8_t lens[320];
     Code lit, dist;
+    // decoder wave -> copier wave: two batches of tokens (below), one being filled while the
+    // other is carried out
+    uint32_t ring[2][kBatch][2];
+    uint32_t count[2];
+    uint32_t stop;              // the trip after which both waves leave the loop
+    uint32_t err;
 };
 
 struct Reader {
@@ -402,186 +412,210 @@ struct TileIn {             // = gcn10_inflate_tile
 };
 static_assert(sizeof(TileIn) == sizeof(gcn10_inflate_tile), "TileIn mirrors the ABI struct");
 
-__global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *comp, const TileIn *tiles, uint32_t n_tiles,
-                                                     uint8_t *scratch, uint32_t slot_bytes, uint32_t *status)
+// Tokens the decoder wave hands to the copier wave, two words each:
+//   literals  a = how many (1..3),              b = their bytes, first one lowest
+//   match     a = 0x80000000 | length,          b = distance
+//   stored    a = 0x40000000 | length (<= 4096), b = offset of the bytes in the stream
+constexpr uint32_t kTokMatch = 0x80000000u, kTokStored = 0x40000000u;
+
+// lane `lane_index` of vec = value (wave-uniform value and index): a compare and a select
+__device__ __forceinline__ uint32_t write_lane(uint32_t vec, uint32_t value, uint32_t lane_index, int lane)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    Shared &sh = *reinterpret_cast<Shared *>(smem);
-    const int lane = threadIdx.x;
-    const uint32_t tile = blockIdx.x;
-    if (tile >= n_tiles)
-        return;
-    const TileIn tin = tiles[tile];
-    const uint32_t in_len = tin.in_len;
+    return (uint32_t)lane == lane_index ? value : vec;
+}
 
+enum { kNeedHeader = 0, kInSymbols = 1, kInStored = 2, kDone = 3 };
+
+struct Decoder {            // the decoder wave's state between batches (all wave-uniform)
     Reader r;
-    r.in = reinterpret_cast<const uint32_t *>(comp + tin.in_off);
-    r.n_dwords = (in_len + 3u) / 4u;
-    r.lane = lane;
-    reader_seek(r, 0);
-    Output o;
-    o.out = scratch + (size_t)tile * slot_bytes;
-    o.limit = tin.out_len < slot_bytes ? tin.out_len : slot_bytes;
-    o.pos = 0;
-    o.flushed = 0;
-    uint32_t err = kOk;
+    uint32_t state;
+    uint32_t e;             // entry of the next literal/length code (kInSymbols)
+    uint32_t pos, limit;    // bytes the tokens so far produce; bytes wanted
+    uint32_t stored_left, stored_at;
+    uint32_t err;
+    bool last;              // the current block is the final one
+    uint32_t in_len;
+};
 
+// Parses a block header (and builds its tables).  Leaves d.state = kInSymbols / kInStored, or
+// kDone with d.err set.
+__device__ __forceinline__ void begin_block(Shared &sh, Decoder &d, int lane)
+{
+    Reader &r = d.r;
     refill(r);
-    {
-        const uint32_t cmf = take_bits(r, 8), flg = take_bits(r, 8);
-        if ((cmf & 15u) != 8u || (cmf >> 4) > 7u || (flg & 0x20u) || ((cmf << 8 | flg) % 31u) != 0u)
-            err = kErrHeader;
-    }
-    bool last = false;
-    while (!err && !last && o.pos < o.limit) {
+    d.last = take_bits(r, 1) != 0;
+    const uint32_t type = take_bits(r, 2);
+    if (type == 0) {
+        // stored: skip to the byte boundary, LEN, NLEN, LEN bytes
+        take_bits(r, r.bc & 7u);
         refill(r);
-        last = take_bits(r, 1) != 0;
-        const uint32_t type = take_bits(r, 2);
-        if (type == 0) {
-            // stored: skip to the byte boundary, LEN, NLEN, LEN bytes
-            take_bits(r, r.bc & 7u);
+        const uint32_t len = take_bits(r, 16);
+        refill(r);
+        const uint32_t nlen = take_bits(r, 16);
+        if ((len ^ nlen) != 0xffffu) {
+            d.err = kErrStored;
+            d.state = kDone;
+            return;
+        }
+        d.stored_at = reader_byte_pos(r);
+        d.stored_left = len;
+        if (d.stored_at + len > d.in_len) {
+            d.err = kErrInput;
+            d.state = kDone;
+            return;
+        }
+        d.state = kInStored;
+        return;
+    }
+    if (type == 3) {
+        d.err = kErrBlockType;
+        d.state = kDone;
+        return;
+    }
+    int n_lit, n_dist;
+    if (type == 1) {
+        // fixed code: lengths 8 / 9 / 7 / 8, 30 distance codes of 5 bits (RFC 1951 3.2.6)
+        for (int i = lane; i < 288; i += 64)
+            sh.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8);
+        if (lane < 32)
+            sh.lens[288 + lane] = 5;
+        n_lit = 288;
+        n_dist = 32;
+    }
+    else {
+        n_lit = (int)take_bits(r, 5) + 257;
+        n_dist = (int)take_bits(r, 5) + 1;
+        const int n_cl = (int)take_bits(r, 4) + 4;
+        if (n_lit > 286 || n_dist > 30) {
+            d.err = kErrLengths;
+            d.state = kDone;
+            return;
+        }
+        // code-length code: 19 symbols of up to 7 bits, table over 7 bits in lit_tab
+        if (lane < 19)
+            sh.lens[lane] = 0;
+        for (int i = 0; i < n_cl; i++) {
             refill(r);
-            const uint32_t len = take_bits(r, 16);
+            const uint32_t v = take_bits(r, 3);
+            // i: 0 1 2 3 | 4 5 6 7 8 9 10 11 12 13 14 15 16 17 18 -> 16 17 18 0 | 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+            const int sym = i < 3 ? 16 + i : i == 3 ? 0 : (i & 1) ? (19 - i) / 2 : 8 + (i - 4) / 2;
+            if (lane == 0)
+                sh.lens[sym] = (uint8_t)v;
+        }
+        if (!sort_code(sh.lens, 19, sh.lit_sorted, sh.lit, lane)) {
+            d.err = kErrLengths;
+            d.state = kDone;
+            return;
+        }
+        fill_table<7, kCodeLengthTable>(sh.lit_tab, sh.lit_sorted, sh.lit, lane);
+        // the n_lit + n_dist code lengths, run-length coded
+        int have = 0;
+        uint32_t prev = 0;
+        const int total = n_lit + n_dist;
+        while (have < total) {
             refill(r);
-            const uint32_t nlen = take_bits(r, 16);
-            if ((len ^ nlen) != 0xffffu) {
-                err = kErrStored;
+            const uint32_t e = uniform(sh.lit_tab[(uint32_t)r.bb & 127u]);
+            if (e == 0) {
+                d.err = kErrLengths;
                 break;
             }
-            uint32_t at = reader_byte_pos(r);
-            if (at + len > in_len) {
-                err = kErrInput;
+            take_bits(r, e & 15u);
+            const uint32_t sym = e >> 4;
+            uint32_t rep = 1, val = sym;
+            if (sym == 16) {
+                if (have == 0) {
+                    d.err = kErrLengths;
+                    break;
+                }
+                rep = 3 + take_bits(r, 2);
+                val = prev;
+            }
+            else if (sym == 17) {
+                rep = 3 + take_bits(r, 3);
+                val = 0;
+            }
+            else if (sym == 18) {
+                rep = 11 + take_bits(r, 7);
+                val = 0;
+            }
+            if (have + (int)rep > total) {
+                d.err = kErrLengths;
                 break;
             }
-            const uint8_t *src = comp + tin.in_off;
-            uint32_t todo = len;
-            while (todo > 0 && o.pos < o.limit) {
-                uint32_t n = todo < 4096u ? todo : 4096u;
-                if (n > o.limit - o.pos)
-                    n = o.limit - o.pos;
-                for (uint32_t k = lane; k < n; k += 64)
-                    sh.window[(o.pos + k) & kWindowMask] = src[at + k];
-                o.pos += n;
-                at += n;
-                todo -= n;
-                if (o.pos - o.flushed >= (uint32_t)kFlush)
-                    flush_half(sh, o, lane);
+            for (uint32_t k = lane; k < rep; k += 64)
+                sh.lens[have + k] = (uint8_t)val;       // lens[] is re-used: the 19 are in the table now
+            have += (int)rep;
+            prev = val;
+        }
+        if (d.err) {
+            d.state = kDone;
+            return;
+        }
+        // distance lengths follow the literal/length ones: move them to lens[288..]
+        {
+            const uint8_t dl = lane < n_dist ? sh.lens[n_lit + lane] : (uint8_t)0;
+            if (lane < 32)
+                sh.lens[288 + lane] = dl;
+            for (int i = n_lit + lane; i < 288; i += 64)
+                sh.lens[i] = 0;
+        }
+        n_lit = 288;
+        n_dist = 32;
+    }
+    if (!sort_code(sh.lens, n_lit, sh.lit_sorted, sh.lit, lane) ||
+        !sort_code(sh.lens + 288, n_dist, sh.dist_sorted, sh.dist, lane)) {
+        d.err = kErrLengths;
+        d.state = kDone;
+        return;
+    }
+    fill_table<kLitRoot, kLitLenTable>(sh.lit_tab, sh.lit_sorted, sh.lit, lane);
+    fill_table<kDistRoot, kDistTable>(sh.dist_tab, sh.dist_sorted, sh.dist, lane);
+    refill(r);
+    d.e = uniform(sh.lit_tab[(uint32_t)r.bb & ((1u << kLitRoot) - 1u)]);
+    d.state = kInSymbols;
+}
+
+// The decoder wave: up to kBatch tokens into `ring`; returns how many.  Every token produces
+// output and output is bounded, every header consumes input and input is bounded, so the
+// stream ends (d.state = kDone) whatever its bits are.
+__device__ __forceinline__ uint32_t decode_batch(Shared &sh, Decoder &d, uint32_t (*ring)[2], int lane)
+{
+    Reader &r = d.r;
+    uint32_t n = 0, ta = 0, tb = 0;
+    while (n < (uint32_t)kBatch && d.state != (uint32_t)kDone) {
+        if (d.state == (uint32_t)kNeedHeader) {
+            if (d.last || d.pos >= d.limit) {
+                d.state = kDone;
+                break;
             }
-            at += todo;
-            reader_seek(r, at >> 2);
-            refill(r);
-            take_bits(r, (at & 3u) * 8u);
+            begin_block(sh, d, lane);
             continue;
         }
-        if (type == 3) {
-            err = kErrBlockType;
-            break;
-        }
-        int n_lit, n_dist;
-        if (type == 1) {
-            // fixed code: lengths 8 / 9 / 7 / 8, 30 distance codes of 5 bits (RFC 1951 3.2.6)
-            for (int i = lane; i < 288; i += 64)
-                sh.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8);
-            if (lane < 32)
-                sh.lens[288 + lane] = 5;
-            n_lit = 288;
-            n_dist = 32;
-        }
-        else {
-            n_lit = (int)take_bits(r, 5) + 257;
-            n_dist = (int)take_bits(r, 5) + 1;
-            const int n_cl = (int)take_bits(r, 4) + 4;
-            if (n_lit > 286 || n_dist > 30) {
-                err = kErrLengths;
-                break;
+        if (d.state == (uint32_t)kInStored) {
+            uint32_t len = d.stored_left < 4096u ? d.stored_left : 4096u;
+            if (len > d.limit - d.pos)
+                len = d.limit - d.pos;
+            if (len > 0) {
+                ta = write_lane(ta, kTokStored | len, n, lane);
+                tb = write_lane(tb, d.stored_at, n, lane);
+                n++;
+                d.pos += len;
             }
-            // code-length code: 19 symbols of up to 7 bits, table over 7 bits in lit_tab
-            if (lane < 19)
-                sh.lens[lane] = 0;
-            for (int i = 0; i < n_cl; i++) {
+            d.stored_at += len;
+            d.stored_left -= len;
+            if (d.stored_left == 0 || d.pos >= d.limit) {
+                const uint32_t at = d.stored_at + d.stored_left;
+                reader_seek(r, at >> 2);
                 refill(r);
-                const uint32_t v = take_bits(r, 3);
-                // order of RFC 1951 3.2.7
-                // i: 0 1 2 3 | 4 5 6 7 8 9 10 11 12 13 14 15 16 17 18 -> 16 17 18 0 | 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
-                const int sym = i < 3 ? 16 + i : i == 3 ? 0 : (i & 1) ? (19 - i) / 2 : 8 + (i - 4) / 2;
-                if (lane == 0)
-                    sh.lens[sym] = (uint8_t)v;
+                take_bits(r, (at & 3u) * 8u);
+                d.state = d.pos >= d.limit ? (uint32_t)kDone : (uint32_t)kNeedHeader;
             }
-            if (!sort_code(sh.lens, 19, sh.lit_sorted, sh.lit, lane)) {
-                err = kErrLengths;
-                break;
-            }
-            fill_table<7, kCodeLengthTable>(sh.lit_tab, sh.lit_sorted, sh.lit, lane);
-            __syncthreads();
-            // the n_lit + n_dist code lengths, run-length coded
-            int have = 0;
-            uint32_t prev = 0;
-            const int total = n_lit + n_dist;
-            while (have < total) {
-                refill(r);
-                const uint32_t e = uniform(sh.lit_tab[(uint32_t)r.bb & 127u]);
-                if (e == 0) {
-                    err = kErrLengths;
-                    break;
-                }
-                take_bits(r, e & 15u);
-                const uint32_t sym = e >> 4;
-                uint32_t rep = 1, val = sym;
-                if (sym == 16) {
-                    if (have == 0) {
-                        err = kErrLengths;
-                        break;
-                    }
-                    rep = 3 + take_bits(r, 2);
-                    val = prev;
-                }
-                else if (sym == 17) {
-                    rep = 3 + take_bits(r, 3);
-                    val = 0;
-                }
-                else if (sym == 18) {
-                    rep = 11 + take_bits(r, 7);
-                    val = 0;
-                }
-                if (have + (int)rep > total) {
-                    err = kErrLengths;
-                    break;
-                }
-                for (uint32_t k = lane; k < rep; k += 64)
-                    sh.lens[have + k] = (uint8_t)val;       // lens[] is re-used: the 19 are in the table now
-                have += (int)rep;
-                prev = val;
-            }
-            if (err)
-                break;
-            // distance lengths follow the literal/length ones: move them to lens[288..]
-            {
-                const uint8_t d = lane < n_dist ? sh.lens[n_lit + lane] : (uint8_t)0;
-                if (lane < 32)
-                    sh.lens[288 + lane] = d;
-                for (int i = n_lit + lane; i < 288; i += 64)
-                    sh.lens[i] = 0;
-            }
-            n_lit = 288;
-            n_dist = 32;
+            continue;
         }
-        if (!sort_code(sh.lens, n_lit, sh.lit_sorted, sh.lit, lane) ||
-            !sort_code(sh.lens + 288, n_dist, sh.dist_sorted, sh.dist, lane)) {
-            err = kErrLengths;
-            break;
-        }
-        fill_table<kLitRoot, kLitLenTable>(sh.lit_tab, sh.lit_sorted, sh.lit, lane);
-        fill_table<kDistRoot, kDistTable>(sh.dist_tab, sh.dist_sorted, sh.dist, lane);
-        __syncthreads();                        // (one wavefront: orders the table writes before the lookups)
-
-        // the block's symbols.  Every trip produces output or leaves the loop, and output is
-        // bounded, so the loop ends whatever the bits are.
-        uint32_t event = o.flushed + (uint32_t)kFlush < o.limit ? o.flushed + (uint32_t)kFlush : o.limit;
-        // The lookup of the NEXT token is issued before the current token's bytes are written,
-        // so its LDS latency overlaps the copy.
-        refill(r);
-        uint32_t e = uniform(sh.lit_tab[(uint32_t)r.bb & ((1u << kLitRoot) - 1u)]);
-        for (;;) {
+        // kInSymbols, a tight loop of its own.  The lookup of the NEXT code is issued as soon as
+        // this one's bits are taken.
+        uint32_t e = d.e;
+        do {
             if (e == 0) {
                 const uint32_t w = uniform(slow_symbol(r, sh.lit_sorted, sh.lit));
                 const uint32_t sym = w >> 4;
@@ -590,61 +624,175 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *comp, const 
                     : sym == 256u ? ((w & 15u) | (uint32_t)kEndOfBlock << 4)
                                   : length_entry(sym, w & 15u);
                 if (e == 0) {
-                    err = kErrCode;
+                    d.err = kErrCode;
+                    d.state = kDone;
                     break;
                 }
             }
             take_bits(r, e & 15u);
             const uint32_t kind = (e >> 4) & 3u;
             if (kind == (uint32_t)kLiterals) {
-                const uint32_t n = (e >> 6) & 3u;
-                const uint32_t lits = e >> 8;
+                const uint32_t cnt = (e >> 6) & 3u;
                 refill(r);
                 const uint32_t next = sh.lit_tab[(uint32_t)r.bb & ((1u << kLitRoot) - 1u)];
-                if ((uint32_t)lane < n)
-                    sh.window[(o.pos + (uint32_t)lane) & kWindowMask] = (uint8_t)(lits >> (8 * lane));
-                o.pos += n;
+                ta = write_lane(ta, cnt, n, lane);
+                tb = write_lane(tb, e >> 8, n, lane);
+                n++;
+                d.pos += cnt;
                 e = uniform(next);
             }
             else if (kind == (uint32_t)kLength) {
                 uint32_t len = ((e >> 9) & 511u) + take_bits(r, (e >> 6) & 7u);
                 refill(r);
-                uint32_t d = uniform(sh.dist_tab[(uint32_t)r.bb & ((1u << kDistRoot) - 1u)]);
-                if (d == 0) {
+                uint32_t de = uniform(sh.dist_tab[(uint32_t)r.bb & ((1u << kDistRoot) - 1u)]);
+                if (de == 0) {
                     const uint32_t w = uniform(slow_symbol(r, sh.dist_sorted, sh.dist));
-                    d = w == 0 ? 0u : dist_entry(w >> 4, w & 15u);
-                    if (d == 0) {
-                        err = kErrCode;
+                    de = w == 0 ? 0u : dist_entry(w >> 4, w & 15u);
+                    if (de == 0) {
+                        d.err = kErrCode;
+                        d.state = kDone;
                         break;
                     }
                 }
-                take_bits(r, d & 15u);
-                const uint32_t dist = ((d >> 8) & 0xffffu) + take_bits(r, (d >> 4) & 15u);
-                if (dist > o.pos) {
-                    err = kErrDistance;
+                take_bits(r, de & 15u);
+                const uint32_t dist = ((de >> 8) & 0xffffu) + take_bits(r, (de >> 4) & 15u);
+                if (dist > d.pos) {
+                    d.err = kErrDistance;
+                    d.state = kDone;
                     break;
                 }
-                if (len > o.limit - o.pos)
-                    len = o.limit - o.pos;
+                if (len > d.limit - d.pos)
+                    len = d.limit - d.pos;
                 refill(r);
                 const uint32_t next = sh.lit_tab[(uint32_t)r.bb & ((1u << kLitRoot) - 1u)];
-                copy_match(sh, o, len, dist, lane);
+                ta = write_lane(ta, kTokMatch | len, n, lane);
+                tb = write_lane(tb, dist, n, lane);
+                n++;
+                d.pos += len;
                 e = uniform(next);
             }
             else {
-                break;                              // end of block
+                d.state = kNeedHeader;              // end of block
+                break;
             }
-            if (o.pos >= event) {
-                if (o.pos - o.flushed >= (uint32_t)kFlush)
-                    flush_half(sh, o, lane);
-                if (o.pos >= o.limit)
-                    break;
-                event = o.flushed + (uint32_t)kFlush < o.limit ? o.flushed + (uint32_t)kFlush : o.limit;
+            if (d.pos >= d.limit) {
+                d.state = kDone;
+                break;
             }
+        } while (n < (uint32_t)kBatch);
+        d.e = e;
+    }
+    if ((uint32_t)lane < n) {
+        ring[lane][0] = ta;
+        ring[lane][1] = tb;
+    }
+    return n;
+}
+
+// The copier wave: carries out a batch of tokens on the window and sends finished halves to HBM.
+__device__ __forceinline__ void copy_batch(Shared &sh, Output &o, const uint32_t (*ring)[2], uint32_t n,
+                                           const uint8_t *stream, int lane)
+{
+    const uint32_t ta = (uint32_t)lane < n ? ring[lane][0] : 0u;
+    const uint32_t tb = (uint32_t)lane < n ? ring[lane][1] : 0u;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)ta, (int)i);
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)tb, (int)i);
+        if (a & kTokMatch) {
+            copy_match(sh, o, a & 0xffffu, b, lane);
+        }
+        else if (a & kTokStored) {
+            const uint32_t len = a & 0xffffu;
+            for (uint32_t k = lane; k < len; k += 64)
+                sh.window[(o.pos + k) & kWindowMask] = stream[b + k];
+            o.pos += len;
+        }
+        else {
+            if ((uint32_t)lane < a)
+                sh.window[(o.pos + (uint32_t)lane) & kWindowMask] = (uint8_t)(b >> (8 * lane));
+            o.pos += a;
+        }
+        if (o.pos - o.flushed >= (uint32_t)kFlush)
+            flush_half(sh, o, lane);
+    }
+}
+
+// One workgroup of two wavefronts per stream: wave 0 decodes bits into tokens, wave 1 carries
+// the tokens out; they swap halves of a small token ring at a barrier every kBatch tokens.
+__global__ __launch_bounds__(128) void inflate_kernel(const uint8_t *comp, const TileIn *tiles, uint32_t n_tiles,
+                                                      uint8_t *scratch, uint32_t slot_bytes, uint32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    Shared &sh = *reinterpret_cast<Shared *>(smem);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t tile = blockIdx.x;
+    if (tile >= n_tiles)
+        return;
+    const TileIn tin = tiles[tile];
+
+    Decoder d;
+    d.r.in = reinterpret_cast<const uint32_t *>(comp + tin.in_off);
+    d.r.n_dwords = (tin.in_len + 3u) / 4u;
+    d.r.lane = lane;
+    d.in_len = tin.in_len;
+    d.state = kNeedHeader;
+    d.e = 0;
+    d.pos = 0;
+    d.limit = tin.out_len < slot_bytes ? tin.out_len : slot_bytes;
+    d.stored_left = d.stored_at = 0;
+    d.err = kOk;
+    d.last = false;
+    Output o;
+    o.out = scratch + (size_t)tile * slot_bytes;
+    o.limit = d.limit;
+    o.pos = 0;
+    o.flushed = 0;
+
+    if (wave == 0) {
+        reader_seek(d.r, 0);
+        refill(d.r);
+        const uint32_t cmf = take_bits(d.r, 8), flg = take_bits(d.r, 8);
+        if ((cmf & 15u) != 8u || (cmf >> 4) > 7u || (flg & 0x20u) || ((cmf << 8 | flg) % 31u) != 0u) {
+            d.err = kErrHeader;
+            d.state = kDone;
+        }
+        if (lane == 0) {
+            sh.stop = 0xffffffffu;
+            sh.err = kOk;
+            sh.count[0] = sh.count[1] = 0;
         }
     }
-    if (!err && reader_byte_pos(r) > in_len + 4u)
-        err = kErrInput;
+    __syncthreads();
+    bool announced = false;
+    for (uint32_t it = 0;; it++) {
+        const uint32_t cur = it & 1u;
+        if (wave == 0) {
+            if (!announced) {
+                const uint32_t n = decode_batch(sh, d, sh.ring[cur], lane);
+                if (lane == 0)
+                    sh.count[cur] = n;
+                if (d.state == (uint32_t)kDone) {
+                    if (!d.err && reader_byte_pos(d.r) > d.in_len + 4u)
+                        d.err = kErrInput;
+                    if (lane == 0) {
+                        sh.stop = it + 1u;          // the copier still has this batch to carry out
+                        sh.err = d.err;
+                    }
+                    announced = true;
+                }
+            }
+        }
+        else if (it > 0) {
+            copy_batch(sh, o, sh.ring[cur ^ 1u], uniform(sh.count[cur ^ 1u]), comp + tin.in_off, lane);
+        }
+        __syncthreads();
+        if (it >= uniform(sh.stop))
+            break;
+    }
+    if (wave == 0)
+        return;
+    uint32_t err = uniform(sh.err);
     if (!err && !window_ok(tin.out_len, tin.chunk_w, tin.src_x, tin.src_y, tin.copy_w, tin.copy_h, slot_bytes))
         err = kErrWindow;
 
@@ -711,10 +859,10 @@ int gcn10_gpu_inflate_tiles(gcn10_gpu_ctx *ctx, const uint8_t *comp_dev, const g
         HIP_TRY(hipMalloc(&ctx->inflate_ws, need));
         ctx->inflate_ws_cap = need;
     }
-    static_assert(sizeof(Shared) <= 40 * 1024, "four inflate wavefronts per CU");
+    static_assert(sizeof(Shared) <= 40 * 1024, "four streams (eight wavefronts) per CU");
     hipStream_t s = as_stream(ctx, stream);
     uint8_t *scratch = reinterpret_cast<uint8_t *>(ctx->inflate_ws);
-    hipLaunchKernelGGL(inflate_kernel, dim3((uint32_t)n_tiles), dim3(64), sizeof(Shared), s, comp_dev,
+    hipLaunchKernelGGL(inflate_kernel, dim3((uint32_t)n_tiles), dim3(128), sizeof(Shared), s, comp_dev,
                        reinterpret_cast<const TileIn *>(tiles_dev), (uint32_t)n_tiles, scratch, slot, status_dev);
     hipLaunchKernelGGL(untile_kernel, dim3((uint32_t)n_tiles, 16), dim3(256), 0, s,
                        reinterpret_cast<const TileIn *>(tiles_dev), scratch, slot, dst_dev,

@@ -1,0 +1,18 @@
+#!/bin/bash
+set -e
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $R/gpurun_out/infl_pmc1 -- python3 $R/tools/bench_inflate.py --pattern natural --reps 1 > $R/gpurun_out/infl_pmc1.log 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES SQ_ACTIVE_INST_SCA --output-format csv -d $R/gpurun_out/infl_pmc2 -- python3 $R/tools/bench_inflate.py --pattern natural --reps 1 > $R/gpurun_out/infl_pmc2.log 2>&1
+python3 - <<'PY'
+import csv, glob, os, collections
+R = os.environ["GRAFT_REPO_ROOT"]
+for d in ("infl_pmc1", "infl_pmc2"):
+    for f in glob.glob(R + "/gpurun_out/%s/*/*counter_collection.csv" % d):
+        acc = collections.defaultdict(lambda: collections.defaultdict(float))
+        for r in csv.DictReader(open(f)):
+            acc[r["Kernel_Name"][:40]][r["Counter_Name"]] += float(r["Counter_Value"])
+        for k, v in acc.items():
+            if "inflate" in k:
+                print(d, k, {a: round(b / 2) for a, b in v.items()})
+PY
