@@ -395,3 +395,38 @@ def test_custom_lookups_with_more_than_256_pixel_classes(tmp_path):
     log = (tmp_path / "logs" / "rank_0.log").read_text()
     assert "more than 256 pixel classes" in log
     _check_block(tmp_path, esa, soil, tabs, 101, BLOCKS[0][1:])
+
+
+@pytest.mark.gpu
+def test_full_size_block_of_the_real_vrt_shape(tmp_path, tables):
+    """One block as the shipped VRT cuts it: 36001 x 36001 pixels (pixel size 8.333...e-05, SURVEY
+    section 7), rows not 16-byte aligned, DEFLATE landcover in 1024 x 1024 tiles.  The whole
+    program runs on it; three of the 18 rasters are decoded by libtiff and compared with the
+    oracle on 600 rows."""
+    import bench
+    Image.MAX_IMAGE_PIXELS = None
+    size, px = 36001, 8.3333333333330430e-05
+    esa, _, coarse, _ = bench.synth_block(5, size, "patches")
+    hs = coarse.shape[0]
+    egt = [0.0, px, 0.0, 3.0, 0.0, -px]
+    sgt = [0.0, 3.0 / hs, 0.0, 3.0, 0.0, -3.0 / hs]
+    tiffutil.write_tiff(str(tmp_path / "esa.tif"), esa, gt=egt, compression=8, tile=(1024, 1024))
+    tiffutil.write_tiff(str(tmp_path / "soil.tif"), coarse, gt=sgt, compression=5, rows_per_strip=16)
+    tiffutil.write_block_shapefile(str(tmp_path / "blocks"), [(1, 0.0, 0.0, 3.0, 3.0)])
+    (tmp_path / "config.txt").write_text(
+        "hysogs_data_path=%s\nesa_data_path=%s\nblocks_shp_path=%s\nlookup_table_path=%s\nlog_dir=%s\n"
+        % (tmp_path / "soil.tif", tmp_path / "esa.tif", tmp_path / "blocks.shp", LOOKUPS, tmp_path / "logs"))
+    out = _run(tmp_path, "-c", "config.txt")
+    assert out.returncode == 0, out.stderr[-2000:]
+    xo, yo, W, H, gt = oc.window(egt, size, size, [0.0, 0.0, 3.0, 3.0])
+    assert (W, H) == (size, size)
+    sxo, syo, hsx, hsy, sg = oc.window(sgt, hs, hs, [0.0, 0.0, 3.0, 3.0])
+    y0 = 20000
+    want = oc.process_block_mem(esa[yo + y0:yo + y0 + 600, xo:xo + W], [gt[0], gt[1], 0.0, gt[3] + y0 * gt[5], 0.0, gt[5]],
+                                coarse[syo:syo + hsy, sxo:sxo + hsx], sg, tables)
+    for r in (0, 13, 17):
+        c, k = divmod(r, 9)
+        p = tmp_path / ("cn_rasters_%s" % CONDS[c]) / ("cn_%s_%s_1.tif" % (HCS[k // 3], ARCS[k % 3]))
+        im = np.array(Image.open(str(p)))
+        assert im.shape == (size, size)
+        assert np.array_equal(im[y0:y0 + 600], want[r]), p
