@@ -12,9 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from gcn10_amd import gpu, host  # noqa: E402
-from tests.conftest import LOOKUPS  # noqa: E402
-from oracle import cn_oracle_c as oc  # noqa: E402
-from oracle import cn_oracle_np as onp  # noqa: E402
+LOOKUPS = os.path.join(ROOT, "tests", "golden", "lookups")
 
 
 def main():
@@ -33,8 +31,7 @@ def main():
     gt = [0.0, 3.0 / W, 0.0, 3.0, 0.0, -3.0 / W]
     sgt = [0.0, 3.0 / hsx, 0.0, 3.0, 0.0, -3.0 / hsx]
     ci, cj = host.build_index_maps(gt, sgt, W, H, hsx, hsy)
-    tabs = np.stack([oc.load_lookup_table(os.path.join(LOOKUPS, "default_lookup_%s_%s.csv" % (hc, arc)))[0]
-                     for hc in onp.HCS for arc in onp.ARCS])
+    tabs = host.load_all_lookup_tables(LOOKUPS)
     res = {"pattern": a.pattern, "rows": H, "W": W, "ms": {}}
     with gpu.Engine(0) as e:
         e.set_tables(tabs)
