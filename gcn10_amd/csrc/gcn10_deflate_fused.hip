@@ -84,12 +84,43 @@ __device__ __forceinline__ uint32_t class_pixels4(const FusedJob &job, uint32_t 
     return out;
 }
 
-// Class ids of one tile position into LDS (row stride kRowStride).
+// Class ids of one tile position into LDS (row stride kRowStride).  `soil_row` holds the soil
+// row cj[y] of the tile's 256 rows (LDS), so that the landcover and soil-code loads of a tile
+// depend on nothing and go out 16 rows at a time.
 __device__ __forceinline__ void load_class_tile(const FusedJob &job, uint32_t tx, uint32_t ty,
-                                                const uint8_t *class_of_lds, uint8_t *tile, int t)
+                                                const uint8_t *class_of_lds, const uint32_t *soil_row,
+                                                uint8_t *tile, int t)
 {
+    typedef uint32_t u32_u __attribute__((aligned(1)));
     const uint32_t x = tx * kTile + (uint32_t)(t & 63) * 4u;
     uint32_t *dst = reinterpret_cast<uint32_t *>(tile) + (t & 63);
+    if ((tx + 1) * kTile <= job.t.W && (ty + 1) * kTile <= job.t.rows) {
+        // interior tile: no edge cases
+        const uint8_t *pe = job.esa + ((size_t)ty * kTile + (uint32_t)(t >> 6)) * job.t.W + x;
+        const uint8_t *ph = job.hx + x;
+        for (int b = 0; b < kTile / 4; b += 16) {
+            uint32_t e4[16], c4[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int r = (b + i) * 4 + (t >> 6);
+                e4[i] = *reinterpret_cast<const u32_u *>(pe + (size_t)(b + i) * 4 * job.t.W);
+                c4[i] = *reinterpret_cast<const u32_u *>(ph + (size_t)soil_row[r] * job.hx_stride);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int r = (b + i) * 4 + (t >> 6);
+                uint32_t out = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) {
+                    const uint32_t lc = (e4[i] >> (8 * q)) & 0xffu;
+                    const uint32_t cc = compact_code((c4[i] >> (8 * q)) & 0xffu);
+                    out |= (uint32_t)class_of_lds[cc * 256u + lc] << (8 * q);
+                }
+                dst[r * (kRowStride / 4)] = out;
+            }
+        }
+        return;
+    }
 #pragma unroll 4
     for (int i = 0; i < kTile / 4; i++) {
         const int r = i * 4 + (t >> 6);
@@ -183,6 +214,7 @@ __device__ __forceinline__ uint32_t wave_sum64(uint32_t v)
 
 struct SharedFA {
     uint8_t tile[kTile * kRowStride];
+    uint32_t soil_row[kTile];           // cj[y] of the tile's rows, clamped
     union {
         uint8_t class_of[gcn10::kClassCodes * 256];     // while the tile is built
         struct {
@@ -211,8 +243,13 @@ __global__ __launch_bounds__(kTile) void fused_stats_kernel(const FusedJob job)
 
     for (int i = t; i < gcn10::kClassCodes * 256 / 4; i += kTile)
         reinterpret_cast<uint32_t *>(sh.class_of)[i] = reinterpret_cast<const uint32_t *>(job.class_of)[i];
+    {
+        const uint32_t y = ty * kTile + (uint32_t)t;
+        uint32_t srow = y < job.t.rows ? (uint32_t)job.cj[y] : 0u;
+        sh.soil_row[t] = srow < job.hx_rows ? srow : job.hx_rows - 1u;
+    }
     __syncthreads();
-    load_class_tile(job, tx, ty, sh.class_of, sh.tile, t);
+    load_class_tile(job, tx, ty, sh.class_of, sh.soil_row, sh.tile, t);
     __syncthreads();
     for (int i = t; i < 288; i += kTile)
         sh.a.lit_hist[i] = 0;
