@@ -458,6 +458,12 @@ __global__ __launch_bounds__(kBuildThreads) void deflate_codes_kernel(const Tile
     Work &w = reinterpret_cast<Work *>(smem)[threadIdx.x];
     const uint32_t *hist = job.hist + (size_t)tile * kHistWords;
     Book *book = reinterpret_cast<Book *>(job.books + (size_t)tile * kBookBytes);
+    if (hist[291] & kAliasFlag) {
+        // the fused encoder found this tile equal to another raster's: nothing to build
+        book->stream_bytes = 0;
+        book->slot = kAliasSlot;
+        return;
+    }
 
     build_code(w, hist, kNumLit, 15, w.lit_len, book->lit_code);
     // the distance alphabet has at most two live symbols: codes 0 and 15
@@ -667,6 +673,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
     const uint32_t *hist = job.hist + (size_t)tile * kHistWords;
     Book *book = reinterpret_cast<Book *>(job.books + (size_t)tile * kBookBytes);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    if (uni(hist[291]) & kAliasFlag) {
+        // the fused encoder found this tile equal to another raster's: nothing to build
+        if (lane == 0) {
+            book->stream_bytes = 0;
+            book->slot = kAliasSlot;
+        }
+        return;
+    }
 
     // ---- statistics: lane holds symbols lane + 64 c ----
     uint32_t h[5];

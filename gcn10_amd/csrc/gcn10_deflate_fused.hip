@@ -335,6 +335,29 @@ __global__ __launch_bounds__(kTile) void fused_stats_kernel(const FusedJob job)
             }
         }
     }
+    // Rasters that cannot differ on this tile: the drained and the undrained raster of a table
+    // map every class that OCCURS here to the same value wherever no dual soil class (A/D .. D/D)
+    // lies under the tile -- most of the world.  The later one becomes an alias of the earlier:
+    // no code construction, no emission, its table entry points at the same bytes.
+    uint32_t alias_of[GCN10_N_RASTERS];
+    {
+        const bool present = sh.a.n_c[t] != 0;
+        for (uint32_t j = 0; j < job.n_sel; j++) {
+            alias_of[j] = 0;
+            const uint32_t r = job.sel[j];
+            if (r < 9u)
+                continue;
+            uint32_t jp = 0xffffffffu;
+            for (uint32_t q = 0; q < j; q++)
+                if (job.sel[q] == r - 9u)
+                    jp = q;
+            if (jp == 0xffffffffu)
+                continue;                           // (uniform: sel[] is a kernel argument)
+            const int differs = present && class_val[r * 256 + t] != class_val[(r - 9u) * 256 + t];
+            if (!__syncthreads_or(differs))
+                alias_of[j] = kAliasFlag | jp;
+        }
+    }
     // per raster: literal counts by VALUE, kGroup rasters per round
     for (uint32_t j0 = 0; j0 < job.n_sel; j0 += kGroup) {
         const uint32_t nj = job.n_sel - j0 < (uint32_t)kGroup ? job.n_sel - j0 : (uint32_t)kGroup;
@@ -361,6 +384,8 @@ __global__ __launch_bounds__(kTile) void fused_stats_kernel(const FusedJob job)
                 else if (i == 290)
                     v = (((65536u % 65521u + sh.a.s2[j] % 65521u) % 65521u) << 16) |
                         ((1u + sh.a.s1[j]) % 65521u);
+                else if (i == 291)
+                    v = alias_of[j];
                 else
                     v = 0u;
                 out[i] = v;
@@ -384,6 +409,22 @@ __device__ __forceinline__ uint32_t wave_scan_dpp(uint32_t x)
     r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
     r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
     return r;
+}
+
+// After pass B: an alias's table entry is its original's.
+__global__ __launch_bounds__(256) void fused_alias_kernel(const FusedJob job)
+{
+    const uint32_t tiles = job.t.across * job.t.down;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= tiles * job.n_sel)
+        return;
+    const uint32_t j = i / tiles, tix = i - j * tiles;
+    const uint32_t a = job.t.hist[(size_t)i * kHistWords + 291];
+    if (a & kAliasFlag) {
+        const size_t from = ((size_t)(a & 0xffu) * tiles + tix) * 2, to = (size_t)i * 2;
+        job.t.table[to] = job.t.table[from];
+        job.t.table[to + 1] = job.t.table[from + 1];
+    }
 }
 
 constexpr int kStageWords = 88;         // 64 tokens x 41 bits, starting anywhere in the first word
@@ -427,7 +468,7 @@ __global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
         int mine = 0, st = 0;
         if ((uint32_t)t < nj) {
             const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)(j0 + t) * tiles + tix) * kBookBytes);
-            mine = b->slot != 0xffffffffu;
+            mine = b->slot < kAliasSlot;             // neither "arena too small" nor an alias
             st = mine && b->stream_bytes == (uint32_t)kMaxStream;
         }
         live = (uint32_t)__ballot(mine);            // threads t < nj are all in wave 0: its ballots are the
@@ -696,6 +737,7 @@ int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W,
     rc = gcn10::deflate_launch_codes(ctx, job.t, (uint32_t)nblocks, s);
     if (rc)
         return rc;
+    hipLaunchKernelGGL(fused_alias_kernel, dim3(((uint32_t)nblocks + 255u) / 256u), dim3(256), 0, s, job);
     const uint32_t groups = (job.n_sel + kGroup - 1) / kGroup;
     hipLaunchKernelGGL(fused_emit_kernel, dim3(positions, groups), dim3(kTile), sizeof(SharedFC), s, job);
     HIP_TRY(hipGetLastError());

@@ -82,6 +82,10 @@ struct Book {
     uint32_t header[64];        // the first header_bits bits of the stream
 };
 constexpr int kBookBytes = (int)sizeof(Book);
+// hist[291] of a (raster, tile): bit 0 = one-value tile (per-raster encoder: value << 8), bit 31 = this
+// raster's tile is byte for byte the tile of selected raster (hist[291] & 0xff) -- fused encoder
+constexpr uint32_t kAliasFlag = 0x80000000u;
+constexpr uint32_t kAliasSlot = 0xfffffffeu;    // Book::slot of an alias (0xffffffff: the arena is too small)
 
 // ------------------------------------------------------------------------
 // match candidates of a tile row as bit masks (passes A and C of both encoders)

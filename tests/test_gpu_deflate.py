@@ -190,6 +190,51 @@ def test_fused_encoder_full_block_width(engine, tables, pattern):
     _fused_case(engine, tables, 512, 36000, seed=21, nasty=False, coherent=False, esa_override=esa)
 
 
+def test_fused_encoder_shares_streams_where_drained_equals_undrained(engine, tables):
+    """No dual soil class (11..14) under a tile: the drained and the undrained raster of a table
+    are the same bytes there, and the fused encoder emits them once -- both table entries point
+    at one stream.  Tiles with a dual class keep two streams."""
+    from gcn10_amd import host
+    from oracle import cn_oracle_c as oc
+    H, W = 512, 768
+    rng = np.random.default_rng(14)
+    small = rng.choice(np.array([10, 20, 30, 40, 50, 60, 80, 90], np.uint8), size=(H // 16, W // 16))
+    esa = np.ascontiguousarray(np.repeat(np.repeat(small, 16, axis=0), 16, axis=1))
+    hsy, hsx = H // 25 + 2, W // 25 + 2
+    coarse = rng.choice(np.array([1, 2, 3, 4], np.uint8), size=(hsy, hsx))
+    coarse[:, hsx // 2:] = rng.choice(np.array([1, 2, 11, 12, 13, 14], np.uint8), size=(hsy, hsx - hsx // 2))
+    gt = [0.0, 0.001, 0.0, 1.0, 0.0, -0.001]
+    sgt = [0.0, 0.025, 0.0, 1.0, 0.0, -0.025]
+    ci, cj = host.build_index_maps(gt, sgt, W, H, hsx, hsy)
+    engine.set_tables(tables)
+    bufs = [engine.upload(a) for a in (esa, coarse, ci, cj)]
+    engine.prepare_tile(bufs[1].ptr, hsx, hsy, bufs[2].ptr, W)
+    data, table, used = engine.deflate_fused(bufs[0].ptr, W, H, bufs[3].ptr)
+    for b in bufs:
+        b.close()
+    want = oc.process_block_mem(esa, gt, coarse, sgt, tables)
+    shared = 0
+    for r in range(18):
+        for ty in range(2):
+            for tx in range(3):
+                off, size = int(table[r, ty, tx, 0]), int(table[r, ty, tx, 1])
+                assert zlib.decompress(data[off:off + size].tobytes()) == \
+                    want[r][ty * 256:(ty + 1) * 256, tx * 256:(tx + 1) * 256].tobytes(), (r, ty, tx)
+                if r >= 9 and off == int(table[r - 9, ty, tx, 0]):
+                    shared += 1
+    # the left tile column has no dual class anywhere near it: 9 tables x 2 tile rows share
+    assert shared >= 18, shared
+    assert all(np.array_equal(want[r][:, :256], want[r - 9][:, :256]) for r in range(9, 18))
+    # where the two rasters differ nothing may be shared
+    for r in range(9, 18):
+        for ty in range(2):
+            for tx in range(3):
+                a = want[r][ty * 256:(ty + 1) * 256, tx * 256:(tx + 1) * 256]
+                b = want[r - 9][ty * 256:(ty + 1) * 256, tx * 256:(tx + 1) * 256]
+                if not np.array_equal(a, b):
+                    assert int(table[r, ty, tx, 0]) != int(table[r - 9, ty, tx, 0])
+
+
 def test_fused_vs_unfused_size(engine, tables):
     """The class-based match structure costs little compression against per-raster parsing."""
     H, W = 512, 768

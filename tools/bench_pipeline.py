@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--gpu-deflate", type=int, default=2)
     ap.add_argument("--workers-per-gpu", type=int, default=0)
     ap.add_argument("--gpu-inflate", type=int, default=1)
+    ap.add_argument("--dual-soil-fraction", type=float, default=-1.0,
+                    help="fraction of the soil cells that keep a dual class (11..14); the others become 1..4. "
+                         "Default: the bench distribution (40 %% dual), unlike most of the real world")
     ap.add_argument("--real-vrt-pixel", action="store_true",
                     help="use the shipped VRT's pixel size 8.3333333333330430e-05: 3-degree blocks become "
                          "36001 px wide (SURVEY.md section 7), rows are not 16-byte aligned")
@@ -78,6 +81,13 @@ def build_world(a, wd, size, nb, px):
                         compression=a.esa_compression, tile=(1024, 1024), bigtiff=esa.size > 3 * 2**30)
     del esa
     hs = coarse1.shape[0]
+    if a.dual_soil_fraction >= 0.0:
+        # dual classes only inside a few large patches, as wet lowlands are
+        rng = np.random.default_rng(12)
+        keep = np.repeat(np.repeat(rng.random(((hs + 95) // 96, (hs + 95) // 96)) < a.dual_soil_fraction, 96, axis=0),
+                         96, axis=1)[:hs, :hs]
+        dual = coarse1 >= 11
+        coarse1 = np.where(dual & ~keep, coarse1 - 10, coarse1).astype(np.uint8)
     soil = np.concatenate([coarse1] * nb, axis=1) if nb > 1 else coarse1
     tiffutil.write_tiff(os.path.join(wd, "soil.tif"), soil, gt=[0.0, 3.0 / hs, 0.0, 3.0, 0.0, -3.0 / hs],
                         compression=8, rows_per_strip=64)
@@ -86,7 +96,7 @@ def build_world(a, wd, size, nb, px):
 
 
 def run_modes(a, wd, size, nb, build_s):
-    res = {"size": size, "blocks": nb, "strip_rows": a.strip_rows, "gpus": a.gpus, "pattern": a.pattern, "gpu_deflate": a.gpu_deflate, "gpu_inflate": a.gpu_inflate, "workers_per_gpu": a.workers_per_gpu, "esa_compression": a.esa_compression,
+    res = {"size": size, "blocks": nb, "strip_rows": a.strip_rows, "gpus": a.gpus, "pattern": a.pattern, "gpu_deflate": a.gpu_deflate, "gpu_inflate": a.gpu_inflate, "workers_per_gpu": a.workers_per_gpu, "esa_compression": a.esa_compression, "dual_soil_fraction": a.dual_soil_fraction,
            "world_build_seconds": round(build_s, 1), "modes": {}}
     for mode in a.modes.split(","):
         env = dict(os.environ)
