@@ -338,6 +338,22 @@ static int ensure_strip_buffers(struct worker *w, int W)
     return 0;
 }
 
+static int ensure_pinned(struct worker *w, void **p, size_t *cap, size_t need)
+{
+    const struct gcn10_gpu_api *g = w->run->gpu;
+
+    if (need <= *cap)
+        return 0;
+    if (*p)
+        g->host_free(w->ctx, *p);
+    *p = NULL;
+    *cap = 0;
+    need += need / 8 + 4096;
+    GPU_TRY(w, g->host_alloc(w->ctx, need, p));
+    *cap = need;
+    return 0;
+}
+
 int gcn10_ensure_dev(struct worker *w, void **p, size_t *cap, size_t need)
 {
     const struct gcn10_gpu_api *g = w->run->gpu;
@@ -417,14 +433,18 @@ static int process_block(struct worker *w, int block_id)
         wlog(w, "ERROR", true, "block %d: %d x %d pixels exceed 2^31-1", block_id, W, H);
         return 0;
     }
-    coarse = malloc((size_t)hsx * (size_t)hsy);
-    ci = malloc((size_t)W * sizeof *ci);
-    cj = malloc((size_t)H * sizeof *cj);
-    if (!coarse || !ci || !cj) {
+    /* soil window and index maps live in pinned memory owned by the worker: their copies to the
+     * GPU need no wait (the previous block, which used the same buffers, has drained) */
+    if (ensure_pinned(w, (void **)&w->h_coarse, &w->h_coarse_cap, (size_t)hsx * (size_t)hsy) != 0 ||
+        ensure_pinned(w, (void **)&w->h_ci, &w->h_ci_cap, (size_t)W * sizeof *ci) != 0 ||
+        ensure_pinned(w, (void **)&w->h_cj, &w->h_cj_cap, (size_t)H * sizeof *cj) != 0) {
         wlog(w, "ERROR", true, "malloc failed for hysogs resampling, block %d", block_id); /* src/cn.c:211 */
         rc = -1;
         goto out;
     }
+    coarse = w->h_coarse;
+    ci = w->h_ci;
+    cj = w->h_cj;
     t_mark = now_seconds();
     /* the soil raster is a global file of full-width strips: a block's window touches ~1440 of
      * them, decoded concurrently on the I/O pool and only as far as the window reaches */
@@ -476,8 +496,7 @@ static int process_block(struct worker *w, int block_id)
     if (g->memcpy_h2d(w->ctx, w->d_coarse, coarse, (size_t)hsx * hsy, w->s_kernel) != 0 ||
         g->memcpy_h2d(w->ctx, w->d_ci, ci, (size_t)W * 4, w->s_kernel) != 0 ||
         g->memcpy_h2d(w->ctx, w->d_cj, cj, (size_t)H * 4, w->s_kernel) != 0 ||
-        g->prepare_tile(w->ctx, w->d_coarse, hsx, hsy, w->d_ci, W, w->s_kernel) != 0 ||
-        g->stream_sync(w->ctx, w->s_kernel) != 0) {    /* host arrays are pageable: finish before reuse */
+        g->prepare_tile(w->ctx, w->d_coarse, hsx, hsy, w->d_ci, W, w->s_kernel) != 0) {
         wlog(w, "ERROR", true, "gpu: %s", g->last_error());
         rc = -1;
         goto out;
@@ -630,6 +649,8 @@ out:
     }
     if (rc != 0 && w->ctx)
         g->device_sync(w->ctx);
+    else if (!ok && w->ctx)
+        g->stream_sync(w->ctx, w->s_kernel);    /* a skipped block: its soil copies may still be queued */
     t_mark = now_seconds();
     for (int k = 0; k < GCN10_N_RASTERS; k++) {
         if (!tifs[k])
@@ -659,9 +680,6 @@ out:
             }
         }
     }
-    free(coarse);
-    free(ci);
-    free(cj);
     return rc;
 }
 
@@ -693,6 +711,9 @@ static void worker_teardown(struct worker *w)
         if (w->h_status) g->host_free(w->ctx, w->h_status);
         if (w->d_status) g->free(w->ctx, w->d_status);
         if (w->d_block) g->free(w->ctx, w->d_block);
+        if (w->h_coarse) g->host_free(w->ctx, w->h_coarse);
+        if (w->h_ci) g->host_free(w->ctx, w->h_ci);
+        if (w->h_cj) g->host_free(w->ctx, w->h_cj);
         if (w->d_coarse) g->free(w->ctx, w->d_coarse);
         if (w->d_ci) g->free(w->ctx, w->d_ci);
         if (w->d_cj) g->free(w->ctx, w->d_cj);

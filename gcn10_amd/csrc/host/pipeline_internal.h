@@ -55,6 +55,9 @@ struct worker {
     int strip_rows;                         /* rows per strip of the current block */
     int n_cus;                              /* compute units of this worker's GPU */
     struct strip_buf buf[MAX_NBUF];         /* the first run->nbuf are in use */
+    uint8_t *h_coarse;                      /* pinned: soil window, index maps of the current block */
+    int32_t *h_ci, *h_cj;
+    size_t h_coarse_cap, h_ci_cap, h_cj_cap;
     uint8_t *d_coarse;
     size_t coarse_cap;
     int32_t *d_ci, *d_cj;
