@@ -10,8 +10,11 @@
 //
 // One workgroup of two wavefronts per stream (RFC 1950 wrapper, RFC 1951 stored / fixed /
 // dynamic blocks): the DECODER wave turns bits into tokens (literals, match, stored run), the
-// COPIER wave carries tokens out on the window; they swap halves of a 2 x 32-token ring at a
-// barrier, so the serial bit decode -- the bound of the whole thing -- never waits for a copy.
+// COPIER wave carries tokens out on the window; they swap halves of a 2 x 64-token ring at a
+// barrier, so the bit decode never waits for a copy.  Inside a block the decoder's lanes decode
+// speculatively -- lane k the token that would start at bit P + k -- and a scalar walk follows
+// the real chain through them (decode_batch), which shrinks the serial part of the decode to a
+// v_readlane and a few scalar instructions per token.
 //   input    each decoder lane holds one dword of a 256-byte piece of the stream (plus the
 //            next piece, already in flight); the bit reader takes dwords with v_readlane at a
 //            wave-uniform index, so the decode state lives in scalar registers
@@ -43,7 +46,7 @@ namespace {
 constexpr int kWindow = 32768;
 constexpr int kWindowMask = kWindow - 1;
 constexpr int kFlush = 16384;
-constexpr int kBatch = 32;              // tokens per hand-over from the decoder to the copier
+constexpr int kBatch = 64;              // token words per hand-over from the decoder to the copier
 constexpr int kLitRoot = 10;
 constexpr int kDistRoot = 9;
 
@@ -87,7 +90,7 @@ struct Shared {
     Code lit, dist;
     // decoder wave -> copier wave: two batches of tokens (below), one being filled while the
     // other is carried out
-    uint32_t ring[2][kBatch][2];
+    uint32_t ring[2][kBatch];
     uint32_t count[2];
     uint32_t stop;              // the trip after which both waves leave the loop
     uint32_t err;
@@ -99,6 +102,7 @@ struct Reader {
     uint32_t ip;            // next dword to take
     uint32_t chunk;         // index of the 64-dword piece held in `cur`
     uint32_t cur, nxt;      // per lane
+    uint32_t prv;           // per lane: the piece before `cur` (the bit buffer may still hold bits of it)
     unsigned long long bb;  // bit buffer, LSB first
     uint32_t bc;            // valid bits in bb
     int lane;
@@ -116,19 +120,37 @@ __device__ __forceinline__ void reader_seek(Reader &r, uint32_t dword)
     r.chunk = dword >> 6;
     r.cur = load_piece(r, r.chunk);
     r.nxt = load_piece(r, r.chunk + 1);
+    r.prv = 0;
     r.bb = 0;
     r.bc = 0;
 }
 
-__device__ __forceinline__ uint32_t take_dword(Reader &r)
+// The stream is held a piece (64 dwords, one per lane) at a time: the piece before the
+// current one, the current one and the next (already in flight).  Pieces only ever advance.
+__device__ __forceinline__ void ensure_piece(Reader &r, uint32_t c)
 {
-    const uint32_t c = r.ip >> 6;
-    if (c != r.chunk) {                     // wave-uniform
+    if (c == r.chunk + 1u) {                    // wave-uniform
+        r.prv = r.cur;
         r.cur = r.nxt;
         r.chunk = c;
         r.nxt = load_piece(r, c + 1);
     }
-    const uint32_t v = __builtin_amdgcn_readlane(r.cur, (int)(r.ip & 63u));
+}
+
+// dword q of the stream as a wave-uniform value (q lies in one of the three pieces)
+__device__ __forceinline__ uint32_t stream_dword(const Reader &r, uint32_t q)
+{
+    const uint32_t in_prv = (uint32_t)__builtin_amdgcn_readlane((int)r.prv, (int)(q & 63u));
+    const uint32_t in_cur = (uint32_t)__builtin_amdgcn_readlane((int)r.cur, (int)(q & 63u));
+    const uint32_t in_nxt = (uint32_t)__builtin_amdgcn_readlane((int)r.nxt, (int)(q & 63u));
+    const uint32_t c = q >> 6;
+    return c == r.chunk ? in_cur : (c + 1u == r.chunk ? in_prv : in_nxt);
+}
+
+__device__ __forceinline__ uint32_t take_dword(Reader &r)
+{
+    ensure_piece(r, r.ip >> 6);
+    const uint32_t v = stream_dword(r, r.ip);
     r.ip++;
     return v;
 }
@@ -412,24 +434,18 @@ struct TileIn {             // = gcn10_inflate_tile
 };
 static_assert(sizeof(TileIn) == sizeof(gcn10_inflate_tile), "TileIn mirrors the ABI struct");
 
-// Tokens the decoder wave hands to the copier wave, two words each:
-//   literals  a = how many (1..3),              b = their bytes, first one lowest
-//   match     a = 0x80000000 | length,          b = distance
-//   stored    a = 0x40000000 | length (<= 4096), b = offset of the bytes in the stream
+// Tokens the decoder wave hands to the copier wave, one word each (a stored run takes two):
+//   literals  how many (1..3) << 24 | their bytes, first one lowest
+//   match     0x80000000 | (length - 3) << 16 | (distance - 1)
+//   stored    0x40000000 | length (<= 4096), then a word with the offset of the bytes in the stream
 constexpr uint32_t kTokMatch = 0x80000000u, kTokStored = 0x40000000u;
-
-// lane `lane_index` of vec = value (wave-uniform value and index): a compare and a select
-__device__ __forceinline__ uint32_t write_lane(uint32_t vec, uint32_t value, uint32_t lane_index, int lane)
-{
-    return (uint32_t)lane == lane_index ? value : vec;
-}
 
 enum { kNeedHeader = 0, kInSymbols = 1, kInStored = 2, kDone = 3 };
 
 struct Decoder {            // the decoder wave's state between batches (all wave-uniform)
     Reader r;
     uint32_t state;
-    uint32_t e;             // entry of the next literal/length code (kInSymbols)
+    uint32_t P;             // kInSymbols: bit position in the stream (the reader's own bit state is stale)
     uint32_t pos, limit;    // bytes the tokens so far produce; bytes wanted
     uint32_t stored_left, stored_at;
     uint32_t err;
@@ -570,18 +586,93 @@ __device__ __forceinline__ void begin_block(Shared &sh, Decoder &d, int lane)
     }
     fill_table<kLitRoot, kLitLenTable>(sh.lit_tab, sh.lit_sorted, sh.lit, lane);
     fill_table<kDistRoot, kDistTable>(sh.dist_tab, sh.dist_sorted, sh.dist, lane);
-    refill(r);
-    d.e = uniform(sh.lit_tab[(uint32_t)r.bb & ((1u << kLitRoot) - 1u)]);
+    d.P = r.ip * 32u - r.bc;
     d.state = kInSymbols;
 }
 
-// The decoder wave: up to kBatch tokens into `ring`; returns how many.  Every token produces
-// output and output is bounded, every header consumes input and input is bounded, so the
-// stream ends (d.state = kDone) whatever its bits are.
-__device__ __forceinline__ uint32_t decode_batch(Shared &sh, Decoder &d, uint32_t (*ring)[2], int lane)
+// the scalar reader at bit P of the stream (P lies in the current piece or the one before)
+__device__ __forceinline__ void seek_bits(Reader &r, uint32_t P)
+{
+    r.ip = P >> 5;
+    r.bb = 0;
+    r.bc = 0;
+    refill(r);
+    take_bits(r, P & 31u);
+}
+
+// One token by the scalar bit reader (codes longer than the tables' roots, or none).  The reader
+// must stand at the token.  Returns false when the block or the stream ends here.
+__device__ __forceinline__ bool scalar_token(Shared &sh, Decoder &d, uint32_t *ring, uint32_t &n, int lane)
 {
     Reader &r = d.r;
-    uint32_t n = 0, ta = 0, tb = 0;
+    refill(r);
+    uint32_t e = uniform(sh.lit_tab[(uint32_t)r.bb & ((1u << kLitRoot) - 1u)]);
+    if (e == 0) {
+        const uint32_t w = uniform(slow_symbol(r, sh.lit_sorted, sh.lit));
+        const uint32_t sym = w >> 4;
+        e = w == 0        ? 0u
+            : sym < 256u  ? ((w & 15u) | 1u << 6 | sym << 8)
+            : sym == 256u ? ((w & 15u) | (uint32_t)kEndOfBlock << 4)
+                          : length_entry(sym, w & 15u);
+        if (e == 0) {
+            d.err = kErrCode;
+            d.state = kDone;
+            return false;
+        }
+    }
+    take_bits(r, e & 15u);
+    const uint32_t kind = (e >> 4) & 3u;
+    uint32_t tok, outl;
+    if (kind == (uint32_t)kLiterals) {
+        outl = (e >> 6) & 3u;
+        tok = outl << 24 | (e >> 8);
+    }
+    else if (kind == (uint32_t)kLength) {
+        const uint32_t len = ((e >> 9) & 511u) + take_bits(r, (e >> 6) & 7u);
+        refill(r);
+        uint32_t de = uniform(sh.dist_tab[(uint32_t)r.bb & ((1u << kDistRoot) - 1u)]);
+        if (de == 0) {
+            const uint32_t w = uniform(slow_symbol(r, sh.dist_sorted, sh.dist));
+            de = w == 0 ? 0u : dist_entry(w >> 4, w & 15u);
+            if (de == 0) {
+                d.err = kErrCode;
+                d.state = kDone;
+                return false;
+            }
+        }
+        take_bits(r, de & 15u);
+        const uint32_t dist = ((de >> 8) & 0xffffu) + take_bits(r, (de >> 4) & 15u);
+        outl = len;
+        tok = kTokMatch | (len - 3u) << 16 | (dist - 1u);
+    }
+    else {
+        d.state = kNeedHeader;                      // end of block
+        return false;
+    }
+    if (lane == 0)
+        ring[n] = tok;
+    n++;
+    d.pos += outl;
+    if (d.pos >= d.limit) {
+        d.state = kDone;
+        return false;
+    }
+    return true;
+}
+
+// The decoder wave: up to kBatch token words into `ring`; returns how many.  Every token
+// produces output and output is bounded, every header consumes input and input is bounded, so
+// the stream ends (d.state = kDone) whatever its bits are.
+//
+// Inside a block the 64 lanes decode SPECULATIVELY: lane k decodes the token that would start at
+// bit P + k (table lookups as gathers, all in vector registers), and a scalar walk then follows
+// the real chain -- start at lane 0, jump by each token's bit count -- collecting the tokens it
+// passes.  The serial part of the decode is that walk: one v_readlane and a few scalar
+// instructions per token instead of two dependent table lookups.
+__device__ __forceinline__ uint32_t decode_batch(Shared &sh, Decoder &d, uint32_t *ring, int lane)
+{
+    Reader &r = d.r;
+    uint32_t n = 0;
     while (n < (uint32_t)kBatch && d.state != (uint32_t)kDone) {
         if (d.state == (uint32_t)kNeedHeader) {
             if (d.last || d.pos >= d.limit) {
@@ -592,13 +683,17 @@ __device__ __forceinline__ uint32_t decode_batch(Shared &sh, Decoder &d, uint32_
             continue;
         }
         if (d.state == (uint32_t)kInStored) {
+            if (n + 2u > (uint32_t)kBatch)
+                break;
             uint32_t len = d.stored_left < 4096u ? d.stored_left : 4096u;
             if (len > d.limit - d.pos)
                 len = d.limit - d.pos;
             if (len > 0) {
-                ta = write_lane(ta, kTokStored | len, n, lane);
-                tb = write_lane(tb, d.stored_at, n, lane);
-                n++;
+                if (lane == 0) {
+                    ring[n] = kTokStored | len;
+                    ring[n + 1] = d.stored_at;
+                }
+                n += 2;
                 d.pos += len;
             }
             d.stored_at += len;
@@ -612,109 +707,143 @@ __device__ __forceinline__ uint32_t decode_batch(Shared &sh, Decoder &d, uint32_
             }
             continue;
         }
-        // kInSymbols, a tight loop of its own.  The lookup of the NEXT code is issued as soon as
-        // this one's bits are taken.
-        uint32_t e = d.e;
-        do {
-            if (e == 0) {
-                const uint32_t w = uniform(slow_symbol(r, sh.lit_sorted, sh.lit));
-                const uint32_t sym = w >> 4;
-                e = w == 0        ? 0u
-                    : sym < 256u  ? ((w & 15u) | 1u << 6 | sym << 8)
-                    : sym == 256u ? ((w & 15u) | (uint32_t)kEndOfBlock << 4)
-                                  : length_entry(sym, w & 15u);
-                if (e == 0) {
-                    d.err = kErrCode;
-                    d.state = kDone;
-                    break;
-                }
+        // ---- kInSymbols: one window of 64 candidate start bits at d.P ----
+        const uint32_t q0 = d.P >> 5;
+        ensure_piece(r, q0 >> 6);
+        uint32_t D0, D1, D2, D3, D4;
+        if ((q0 & 63u) <= 59u) {
+            // the usual case: all five dwords in one piece, one select for all of them
+            const uint32_t piece = (q0 >> 6) == r.chunk ? r.cur : r.prv;
+            const int l0 = (int)(q0 & 63u);
+            D0 = (uint32_t)__builtin_amdgcn_readlane((int)piece, l0);
+            D1 = (uint32_t)__builtin_amdgcn_readlane((int)piece, l0 + 1);
+            D2 = (uint32_t)__builtin_amdgcn_readlane((int)piece, l0 + 2);
+            D3 = (uint32_t)__builtin_amdgcn_readlane((int)piece, l0 + 3);
+            D4 = (uint32_t)__builtin_amdgcn_readlane((int)piece, l0 + 4);
+        }
+        else {
+            D0 = stream_dword(r, q0);
+            D1 = stream_dword(r, q0 + 1);
+            D2 = stream_dword(r, q0 + 2);
+            D3 = stream_dword(r, q0 + 3);
+            D4 = stream_dword(r, q0 + 4);
+        }
+        const uint32_t rel = (d.P & 31u) + (uint32_t)lane;          // < 95
+        const uint32_t o = rel >> 5, sft = rel & 31u;
+        const uint32_t a = o == 0 ? D0 : o == 1 ? D1 : D2;
+        const uint32_t b = o == 0 ? D1 : o == 1 ? D2 : D3;
+        const uint32_t c = o == 0 ? D2 : o == 1 ? D3 : D4;
+        const uint32_t lo = __builtin_amdgcn_alignbit(b, a, sft);   // bits P+lane .. +31
+        const uint32_t hi = __builtin_amdgcn_alignbit(c, b, sft);   //          +32 .. +63
+        const uint32_t e1 = sh.lit_tab[lo & ((1u << kLitRoot) - 1u)];
+        const uint32_t cl = e1 & 15u, kind = (e1 >> 4) & 3u;
+        uint32_t bits = cl, outl = (e1 >> 6) & 3u;
+        uint32_t tok = outl << 24 | (e1 >> 8);
+        uint32_t special = e1 == 0 ? 2u : (kind == (uint32_t)kEndOfBlock ? 1u : 0u);
+        {
+            // as if it were a match (harmless where it is not: the lookups stay in the tables)
+            const uint32_t eb = (e1 >> 6) & 7u;
+            const uint32_t len = ((e1 >> 9) & 511u) + ((lo >> cl) & ((1u << eb) - 1u));
+            const uint32_t t = cl + eb;                             // <= 20
+            const uint32_t x2 = __builtin_amdgcn_alignbit(hi, lo, t);
+            const uint32_t de = sh.dist_tab[x2 & ((1u << kDistRoot) - 1u)];
+            const uint32_t dl = de & 15u, deb = (de >> 4) & 15u;
+            const uint32_t dist = ((de >> 8) & 0xffffu) + ((x2 >> dl) & ((1u << deb) - 1u));
+            if (kind == (uint32_t)kLength && e1 != 0) {
+                bits = t + dl + deb;                                // <= 48
+                outl = len;
+                tok = kTokMatch | ((len - 3u) & 255u) << 16 | ((dist - 1u) & 0xffffu);
+                if (de == 0)
+                    special = 2u;
             }
-            take_bits(r, e & 15u);
-            const uint32_t kind = (e >> 4) & 3u;
-            if (kind == (uint32_t)kLiterals) {
-                const uint32_t cnt = (e >> 6) & 3u;
-                refill(r);
-                const uint32_t next = sh.lit_tab[(uint32_t)r.bb & ((1u << kLitRoot) - 1u)];
-                ta = write_lane(ta, cnt, n, lane);
-                tb = write_lane(tb, e >> 8, n, lane);
-                n++;
-                d.pos += cnt;
-                e = uniform(next);
+        }
+        const uint32_t info = bits | outl << 6 | special << 15;     // 6 + 9 + 2 bits
+        // ---- the chain: from bit 0 of the window, token by token ----
+        uint32_t k = 0, n_new = 0, src = 0, stop = 0;
+        while (k < 64u && n + n_new < (uint32_t)kBatch) {
+            const uint32_t inf = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)k);
+            stop = inf >> 15;
+            if (stop)
+                break;
+            src = (uint32_t)lane == n_new ? k : src;
+            n_new++;
+            d.pos += (inf >> 6) & 511u;
+            k += inf & 63u;
+            if (d.pos >= d.limit) {
+                stop = 4u;
+                break;
             }
-            else if (kind == (uint32_t)kLength) {
-                uint32_t len = ((e >> 9) & 511u) + take_bits(r, (e >> 6) & 7u);
-                refill(r);
-                uint32_t de = uniform(sh.dist_tab[(uint32_t)r.bb & ((1u << kDistRoot) - 1u)]);
-                if (de == 0) {
-                    const uint32_t w = uniform(slow_symbol(r, sh.dist_sorted, sh.dist));
-                    de = w == 0 ? 0u : dist_entry(w >> 4, w & 15u);
-                    if (de == 0) {
-                        d.err = kErrCode;
-                        d.state = kDone;
-                        break;
-                    }
-                }
-                take_bits(r, de & 15u);
-                const uint32_t dist = ((de >> 8) & 0xffffu) + take_bits(r, (de >> 4) & 15u);
-                if (dist > d.pos) {
-                    d.err = kErrDistance;
-                    d.state = kDone;
-                    break;
-                }
-                if (len > d.limit - d.pos)
-                    len = d.limit - d.pos;
-                refill(r);
-                const uint32_t next = sh.lit_tab[(uint32_t)r.bb & ((1u << kLitRoot) - 1u)];
-                ta = write_lane(ta, kTokMatch | len, n, lane);
-                tb = write_lane(tb, dist, n, lane);
-                n++;
-                d.pos += len;
-                e = uniform(next);
+        }
+        {
+            const uint32_t mine = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)tok);
+            if ((uint32_t)lane < n_new)
+                ring[n + (uint32_t)lane] = mine;
+            n += n_new;
+        }
+        d.P += k;
+        if (stop == 4u) {
+            d.state = kDone;
+        }
+        else if (stop == 1u) {
+            // end of block at lane k: take its code, the next header is read by the scalar reader
+            d.P += (uint32_t)__builtin_amdgcn_readlane((int)info, (int)k) & 63u;
+            seek_bits(r, d.P);
+            d.state = kNeedHeader;
+        }
+        else if (stop == 2u) {
+            // a code the tables do not hold (or none): that one token by the scalar reader
+            if (n < (uint32_t)kBatch) {
+                seek_bits(r, d.P);
+                if (scalar_token(sh, d, ring, n, lane) || d.state == (uint32_t)kNeedHeader)
+                    d.P = r.ip * 32u - r.bc;
             }
             else {
-                d.state = kNeedHeader;              // end of block
-                break;
+                break;                              // no room: the next batch starts with it
             }
-            if (d.pos >= d.limit) {
-                d.state = kDone;
-                break;
-            }
-        } while (n < (uint32_t)kBatch);
-        d.e = e;
-    }
-    if ((uint32_t)lane < n) {
-        ring[lane][0] = ta;
-        ring[lane][1] = tb;
+        }
+        if (d.state == (uint32_t)kDone)
+            seek_bits(r, d.P);                      // (for the end-of-input check)
     }
     return n;
 }
 
 // The copier wave: carries out a batch of tokens on the window and sends finished halves to HBM.
-__device__ __forceinline__ void copy_batch(Shared &sh, Output &o, const uint32_t (*ring)[2], uint32_t n,
-                                           const uint8_t *stream, int lane)
+// Returns 0, or the reason a token cannot be carried out (a distance before the start).
+__device__ __forceinline__ uint32_t copy_batch(Shared &sh, Output &o, const uint32_t *ring, uint32_t n,
+                                               const uint8_t *stream, int lane)
 {
-    const uint32_t ta = (uint32_t)lane < n ? ring[lane][0] : 0u;
-    const uint32_t tb = (uint32_t)lane < n ? ring[lane][1] : 0u;
+    const uint32_t tk = (uint32_t)lane < n ? ring[lane] : 0u;
     for (uint32_t i = 0; i < n; i++) {
-        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)ta, (int)i);
-        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)tb, (int)i);
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)tk, (int)i);
+        if (o.pos >= o.limit)
+            break;
         if (a & kTokMatch) {
-            copy_match(sh, o, a & 0xffffu, b, lane);
+            uint32_t len = ((a >> 16) & 255u) + 3u;
+            const uint32_t dist = (a & 0xffffu) + 1u;
+            if (dist > o.pos)
+                return kErrDistance;
+            if (len > o.limit - o.pos)
+                len = o.limit - o.pos;
+            copy_match(sh, o, len, dist, lane);
         }
         else if (a & kTokStored) {
             const uint32_t len = a & 0xffffu;
+            i++;
+            const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)tk, (int)i);
             for (uint32_t k = lane; k < len; k += 64)
-                sh.window[(o.pos + k) & kWindowMask] = stream[b + k];
+                sh.window[(o.pos + k) & kWindowMask] = stream[at + k];
             o.pos += len;
         }
         else {
-            if ((uint32_t)lane < a)
-                sh.window[(o.pos + (uint32_t)lane) & kWindowMask] = (uint8_t)(b >> (8 * lane));
-            o.pos += a;
+            const uint32_t cnt = a >> 24;
+            if ((uint32_t)lane < cnt)
+                sh.window[(o.pos + (uint32_t)lane) & kWindowMask] = (uint8_t)(a >> (8 * lane));
+            o.pos += cnt;
         }
         if (o.pos - o.flushed >= (uint32_t)kFlush)
             flush_half(sh, o, lane);
     }
+    return 0;
 }
 
 // One workgroup of two wavefronts per stream: wave 0 decodes bits into tokens, wave 1 carries
@@ -737,7 +866,7 @@ __global__ __launch_bounds__(128) void inflate_kernel(const uint8_t *comp, const
     d.r.lane = lane;
     d.in_len = tin.in_len;
     d.state = kNeedHeader;
-    d.e = 0;
+    d.P = 0;
     d.pos = 0;
     d.limit = tin.out_len < slot_bytes ? tin.out_len : slot_bytes;
     d.stored_left = d.stored_at = 0;
@@ -765,6 +894,7 @@ __global__ __launch_bounds__(128) void inflate_kernel(const uint8_t *comp, const
     }
     __syncthreads();
     bool announced = false;
+    uint32_t c_err = 0;
     for (uint32_t it = 0;; it++) {
         const uint32_t cur = it & 1u;
         if (wave == 0) {
@@ -783,8 +913,8 @@ __global__ __launch_bounds__(128) void inflate_kernel(const uint8_t *comp, const
                 }
             }
         }
-        else if (it > 0) {
-            copy_batch(sh, o, sh.ring[cur ^ 1u], uniform(sh.count[cur ^ 1u]), comp + tin.in_off, lane);
+        else if (it > 0 && c_err == 0) {
+            c_err = copy_batch(sh, o, sh.ring[cur ^ 1u], uniform(sh.count[cur ^ 1u]), comp + tin.in_off, lane);
         }
         __syncthreads();
         if (it >= uniform(sh.stop))
@@ -792,7 +922,7 @@ __global__ __launch_bounds__(128) void inflate_kernel(const uint8_t *comp, const
     }
     if (wave == 0)
         return;
-    uint32_t err = uniform(sh.err);
+    uint32_t err = c_err ? c_err : uniform(sh.err);
     if (!err && !window_ok(tin.out_len, tin.chunk_w, tin.src_x, tin.src_y, tin.copy_w, tin.copy_h, slot_bytes))
         err = kErrWindow;
 
