@@ -241,6 +241,8 @@ __global__ __launch_bounds__(kTile) void fused_stats_kernel(const FusedJob job)
     const uint32_t ty = tix / job.t.across, tx = tix - ty * job.t.across;
     const uint8_t *class_val = job.class_of + gcn10::kClassCodes * 256;
 
+    if (tix == 0 && t == 0)
+        *job.t.cursor = 0ull;                       // pass B reserves arena slots from here
     for (int i = t; i < gcn10::kClassCodes * 256 / 4; i += kTile)
         reinterpret_cast<uint32_t *>(sh.class_of)[i] = reinterpret_cast<const uint32_t *>(job.class_of)[i];
     {
@@ -411,22 +413,6 @@ __device__ __forceinline__ uint32_t wave_scan_dpp(uint32_t x)
     return r;
 }
 
-// After pass B: an alias's table entry is its original's.
-__global__ __launch_bounds__(256) void fused_alias_kernel(const FusedJob job)
-{
-    const uint32_t tiles = job.t.across * job.t.down;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= tiles * job.n_sel)
-        return;
-    const uint32_t j = i / tiles, tix = i - j * tiles;
-    const uint32_t a = job.t.hist[(size_t)i * kHistWords + 291];
-    if (a & kAliasFlag) {
-        const size_t from = ((size_t)(a & 0xffu) * tiles + tix) * 2, to = (size_t)i * 2;
-        job.t.table[to] = job.t.table[from];
-        job.t.table[to + 1] = job.t.table[from + 1];
-    }
-}
-
 constexpr int kStageWords = 88;         // 64 tokens x 41 bits, starting anywhere in the first word
 
 struct SharedFC {
@@ -470,6 +456,13 @@ __global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
             const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)(j0 + t) * tiles + tix) * kBookBytes);
             mine = b->slot < kAliasSlot;             // neither "arena too small" nor an alias
             st = mine && b->stream_bytes == (uint32_t)kMaxStream;
+            // an alias's table entry is its original's (written by pass B, a launch ago)
+            const uint32_t al = job.t.hist[((size_t)(j0 + t) * tiles + tix) * kHistWords + 291];
+            if (al & kAliasFlag) {
+                const size_t from = ((size_t)(al & 0xffu) * tiles + tix) * 2, to = ((size_t)(j0 + t) * tiles + tix) * 2;
+                job.t.table[to] = job.t.table[from];
+                job.t.table[to + 1] = job.t.table[from + 1];
+            }
         }
         live = (uint32_t)__ballot(mine);            // threads t < nj are all in wave 0: its ballots are the
         stored_mask = (uint32_t)__ballot(st);       // masks, the other waves get them through LDS
@@ -732,12 +725,10 @@ int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W,
         ctx->fused_ready = true;
     }
     hipStream_t s = as_stream(ctx, stream);
-    HIP_TRY(hipMemsetAsync(cursor_dev, 0, sizeof(unsigned long long), s));
     hipLaunchKernelGGL(fused_stats_kernel, dim3(positions), dim3(kTile), sizeof(SharedFA), s, job);
     rc = gcn10::deflate_launch_codes(ctx, job.t, (uint32_t)nblocks, s);
     if (rc)
         return rc;
-    hipLaunchKernelGGL(fused_alias_kernel, dim3(((uint32_t)nblocks + 255u) / 256u), dim3(256), 0, s, job);
     const uint32_t groups = (job.n_sel + kGroup - 1) / kGroup;
     hipLaunchKernelGGL(fused_emit_kernel, dim3(positions, groups), dim3(kTile), sizeof(SharedFC), s, job);
     HIP_TRY(hipGetLastError());
