@@ -27,8 +27,14 @@ namespace {
 // (24.6 GB written + 2 x 23.3 GB read per block in the unfused path -> 1.4 GB read).
 // A match of the class stream is a match in every raster; a raster's own extra repeats
 // (two classes with the same value in that raster) are coded as literals, which costs a
-// little compression.  Passes: F-A statistics per tile position -> B code construction
-// per (raster, tile), unchanged -> F-C emission per tile position, looping over rasters.
+// little compression.  Three launches per strip:
+//   F-A  one workgroup per tile position: class tile, match masks, greedy parse of every
+//        row, the position's 16-bit token stream -> workspace; per raster the literal
+//        statistics (class counts mapped through class_val) and the Adler-32 (per-class
+//        pixel counts and position-weight sums); drained/undrained aliases
+//   B    code construction per (raster, tile), the per-raster encoder's pass unchanged
+//   F-C  one workgroup per (position, group of kGroup rasters), token-parallel: prefix sums
+//        of the tokens' code lengths place their bits, words go straight to the arena
 // ------------------------------------------------------------------------
 constexpr int kGroup = 6;            // rasters emitted by one workgroup of pass F-C
 
