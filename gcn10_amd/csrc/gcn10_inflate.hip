@@ -757,23 +757,26 @@ __device__ __forceinline__ uint32_t decode_batch(Shared &sh, Decoder &d, uint32_
                     special = 2u;
             }
         }
-        const uint32_t info = bits | outl << 6 | special << 15;     // 6 + 9 + 2 bits
-        // ---- the chain: from bit 0 of the window, token by token ----
+        // bits | bytes produced << 6 for a token the walk passes; reason << 15 for one it stops at:
+        // an end of block (with its bits, which the walk takes) or a code the tables do not hold
+        // (no bits: the scalar reader starts at it)
+        const uint32_t info = special == 2u ? 2u << 15 : special == 1u ? (cl | 1u << 15) : (bits | outl << 6);
+        // ---- the chain: from bit 0 of the window, token by token.  One exit, no branches in the
+        // body: the loop is the serial core of the decoder ----
         uint32_t k = 0, n_new = 0, src = 0, stop = 0;
-        while (k < 64u && n + n_new < (uint32_t)kBatch) {
+        const uint32_t room = (uint32_t)kBatch - n;
+        bool go = true;
+        while (go) {
             const uint32_t inf = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)k);
-            stop = inf >> 15;
-            if (stop)
-                break;
-            src = (uint32_t)lane == n_new ? k : src;
-            n_new++;
+            src = (uint32_t)lane == n_new ? k : src;    // (a stop token's entry lies beyond n_new: unused)
+            n_new += inf < 0x8000u ? 1u : 0u;
             d.pos += (inf >> 6) & 511u;
             k += inf & 63u;
-            if (d.pos >= d.limit) {
-                stop = 4u;
-                break;
-            }
+            stop = inf >> 15;
+            go = (stop == 0u) & (d.pos < d.limit) & (n_new < room) & (k < 64u);
         }
+        if (stop == 0u && d.pos >= d.limit)
+            stop = 4u;
         {
             const uint32_t mine = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)tok);
             if ((uint32_t)lane < n_new)
@@ -785,8 +788,7 @@ __device__ __forceinline__ uint32_t decode_batch(Shared &sh, Decoder &d, uint32_
             d.state = kDone;
         }
         else if (stop == 1u) {
-            // end of block at lane k: take its code, the next header is read by the scalar reader
-            d.P += (uint32_t)__builtin_amdgcn_readlane((int)info, (int)k) & 63u;
+            // end of block (its code is taken): the next header is read by the scalar reader
             seek_bits(r, d.P);
             d.state = kNeedHeader;
         }
