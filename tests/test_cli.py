@@ -263,12 +263,15 @@ def test_vrt_landcover_with_local_tile_mirror(tmp_path, tables):
 
 
 @pytest.mark.gpu
-def test_compressed_tiles_spill_past_the_pinned_arena(tmp_path, tables):
+@pytest.mark.parametrize("buffers", ["2", "4"])
+def test_compressed_tiles_spill_past_the_pinned_arena(tmp_path, tables, buffers):
     """The pinned arena holds an eighth of the encoder's worst case; a strip that needs more goes
-    through a pageable buffer.  Forced here with a 64 KB arena: results must not change."""
+    through a pageable buffer.  Forced here with a 64 KB arena: results must not change.  Also the
+    two other strip-buffer counts (the default is three)."""
     esa, soil = _world(tmp_path, seed=41)
     (tmp_path / "ids.txt").write_text("101\n")
-    out = _run(tmp_path, "-c", "config.txt", "-l", "ids.txt", env={"GCN10_PINNED_ARENA_BYTES": "65536"})
+    out = _run(tmp_path, "-c", "config.txt", "-l", "ids.txt",
+               env={"GCN10_PINNED_ARENA_BYTES": "65536", "GCN10_STRIP_BUFFERS": buffers})
     assert out.returncode == 0, out.stderr[-2000:]
     bid, *bbox = BLOCKS[0]
     xo, yo, W, H, gt = oc.window(ESA_GT, 3000, 2000, bbox)
