@@ -109,20 +109,34 @@ static void put_tiles_job(void *arg)
 {
     struct put_job *j = arg;
     const uint32_t *tab = j->b->h_table + (size_t)j->raster * (size_t)j->across * (size_t)j->down * 2;
+    const size_t n = (size_t)j->across * (size_t)j->down;
+    int *txs = malloc(n * sizeof *txs), *tys = malloc(n * sizeof *tys);
+    const void **data = malloc(n * sizeof *data);
+    uint32_t *sizes = malloc(n * sizeof *sizes);
+    bool ok = txs && tys && data && sizes;
 
-    for (int ty = 0; ty < j->down; ty++) {
+    for (int ty = 0; ok && ty < j->down; ty++) {
         for (int tx = 0; tx < j->across; tx++) {
-            const uint32_t off = tab[((size_t)ty * j->across + tx) * 2];
-            const uint32_t size = tab[((size_t)ty * j->across + tx) * 2 + 1];
+            const size_t i = (size_t)ty * j->across + tx;
+            const uint32_t off = tab[i * 2], size = tab[i * 2 + 1];
 
-            if (off == 0xffffffffu || size == 0 || (size_t)off + size > j->b->arena_cap ||
-                gcn10_tiff_put_tile(j->tif, tx, j->ty0 + ty, j->b->h_tiles + off, size) != 0) {
-                atomic_store(&j->w->failed, true);
-                goto done;
+            if (off == 0xffffffffu || size == 0 || (size_t)off + size > j->b->arena_cap) {
+                ok = false;
+                break;
             }
+            txs[i] = tx;
+            tys[i] = j->ty0 + ty;
+            data[i] = j->b->h_tiles + off;
+            sizes[i] = size;
         }
     }
-done:
+    /* the strip's tiles of this raster: gathered writes, 512 tiles per system call */
+    if (!ok || gcn10_tiff_put_tiles(j->tif, (int)n, txs, tys, data, sizes) != 0)
+        atomic_store(&j->w->failed, true);
+    free(txs);
+    free(tys);
+    free(data);
+    free(sizes);
     pthread_mutex_lock(&j->b->mu);
     if (--j->b->pending == 0)
         pthread_cond_broadcast(&j->b->cv);

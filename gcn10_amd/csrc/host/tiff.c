@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -956,6 +957,69 @@ int gcn10_tiff_put_tile(gcn10_tiff_writer *w, int tx, int ty, const void *zdata,
         w->counts[idx] = (uint32_t)nbytes;
         w->pos += nbytes;
     }
+    pthread_mutex_unlock(&w->mu);
+    return rc;
+}
+
+/* Many tiles of one raster at once (a strip's worth from the GPU encoder): one pwritev per
+ * 1024 tiles instead of a pwrite per tile -- a block has 358 000 of them. */
+int gcn10_tiff_put_tiles(gcn10_tiff_writer *w, int n, const int *tx, const int *ty, const void *const *zdata,
+                         const uint32_t *nbytes)
+{
+    struct iovec iov[512];
+    int rc = 0;
+
+    pthread_mutex_lock(&w->mu);
+    for (int i = 0; i < n && rc == 0;) {
+        int m = 0;
+        uint64_t total = 0, at = w->pos;
+
+        for (; i + m < n && m < 512; m++) {
+            if (tx[i + m] < 0 || ty[i + m] < 0 || tx[i + m] >= w->across || ty[i + m] >= w->down ||
+                nbytes[i + m] == 0) {
+                rc = -1;
+                break;
+            }
+            iov[m].iov_base = (void *)zdata[i + m];
+            iov[m].iov_len = nbytes[i + m];
+            total += nbytes[i + m];
+        }
+        if (rc != 0)
+            break;
+        if (w->pos + total + (1u << 20) > 0xffffffffull) {
+            rc = -1;                    /* classic TIFF offsets are 32 bit */
+            break;
+        }
+        for (int k = 0; k < m;) {       /* pwritev may stop short */
+            ssize_t got = pwritev(w->fd, iov + k, m - k, (off_t)at);
+
+            if (got < 0 && errno == EINTR)
+                continue;
+            if (got <= 0) {
+                rc = -1;
+                break;
+            }
+            at += (uint64_t)got;
+            while (k < m && (size_t)got >= iov[k].iov_len)
+                got -= (ssize_t)iov[k++].iov_len;
+            if (k < m && got > 0) {
+                iov[k].iov_base = (char *)iov[k].iov_base + got;
+                iov[k].iov_len -= (size_t)got;
+            }
+        }
+        if (rc != 0)
+            break;
+        for (int k = 0; k < m; k++) {
+            size_t idx = (size_t)ty[i + k] * (size_t)w->across + (size_t)tx[i + k];
+
+            w->offsets[idx] = (uint32_t)w->pos;
+            w->counts[idx] = nbytes[i + k];
+            w->pos += nbytes[i + k];
+        }
+        i += m;
+    }
+    if (rc != 0)
+        w->failed = true;
     pthread_mutex_unlock(&w->mu);
     return rc;
 }

@@ -178,6 +178,9 @@ int gcn10_tiff_tiles_across(const gcn10_tiff_writer *w);
 int gcn10_tiff_tiles_down(const gcn10_tiff_writer *w);
 /* Appends one compressed tile (tx, ty) of `nbytes` zlib-stream bytes. */
 int gcn10_tiff_put_tile(gcn10_tiff_writer *w, int tx, int ty, const void *zdata, size_t nbytes);
+/* n tiles of the raster in one go (gathered writes); same result as n gcn10_tiff_put_tile calls */
+int gcn10_tiff_put_tiles(gcn10_tiff_writer *w, int n, const int *tx, const int *ty,
+                         const void *const *zdata, const uint32_t *nbytes);
 /* Writes the directory and closes the file.  0 or -1. */
 int gcn10_tiff_finish(gcn10_tiff_writer *w, char *err, size_t errcap);
 void gcn10_tiff_abort(gcn10_tiff_writer *w);

@@ -370,3 +370,50 @@ def test_read_plan_of_a_vrt_mosaic(tmp_path):
     # a NODATA other than the background value needs the host reader's transparency
     with vrt([("a.tif", 0, 40, 7)]) as r:
         assert r.plan(0, 0, 40, 60) is None
+
+
+def test_tiff_writer_gathered_tile_writes(tmp_path):
+    """gcn10_tiff_put_tiles (the GPU pipeline's sink: a strip's tiles of one raster per call) writes
+    what gcn10_tiff_put_tile would, in any tile order, across its 512-tile batches."""
+    import ctypes as C
+    import zlib
+    L = host.lib()
+    L.gcn10_tiff_create.restype = C.c_void_p
+    L.gcn10_tiff_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.c_char_p, C.c_size_t]
+    L.gcn10_tiff_put_tiles.restype = C.c_int
+    L.gcn10_tiff_put_tiles.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                       C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
+    L.gcn10_tiff_finish.restype = C.c_int
+    L.gcn10_tiff_finish.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    W, H = 256 * 40 + 17, 256 * 15 + 3                  # 41 x 16 = 656 tiles: two batches
+    rng = np.random.default_rng(3)
+    img = np.repeat(np.repeat(rng.integers(0, 200, (H // 64 + 1, W // 64 + 1), dtype=np.uint8), 64, axis=0), 64, axis=1)[:H, :W]
+    gt = (C.c_double * 6)(*GT)
+    err = C.create_string_buffer(512)
+    p = str(tmp_path / "w.tif")
+    w = L.gcn10_tiff_create(p.encode(), W, H, gt, None, err, 512)
+    assert w, err.value
+    across, down = (W + 255) // 256, (H + 255) // 256
+    order = rng.permutation(across * down)
+    blobs, txs, tys = [], [], []
+    for idx in order:
+        ty, tx = divmod(int(idx), across)
+        tile = np.zeros((256, 256), np.uint8)
+        part = img[ty * 256:(ty + 1) * 256, tx * 256:(tx + 1) * 256]
+        tile[:part.shape[0], :part.shape[1]] = part
+        blobs.append(zlib.compress(tile.tobytes(), 1))
+        txs.append(tx)
+        tys.append(ty)
+    n = len(blobs)
+    bufs = [C.create_string_buffer(b, len(b)) for b in blobs]
+    ptrs = (C.c_void_p * n)(*[C.cast(b, C.c_void_p).value for b in bufs])
+    sizes = (C.c_uint32 * n)(*[len(b) for b in blobs])
+    assert L.gcn10_tiff_put_tiles(w, n, (C.c_int * n)(*txs), (C.c_int * n)(*tys), ptrs, sizes) == 0
+    assert L.gcn10_tiff_finish(w, err, 512) == 0, err.value
+    Image.MAX_IMAGE_PIXELS = None
+    assert np.array_equal(np.array(Image.open(p)), img)
+    assert not os.path.exists(p + ".part")
+    # a tile outside the raster is refused and fails the file
+    w = L.gcn10_tiff_create(p.encode(), 300, 300, gt, None, err, 512)
+    assert L.gcn10_tiff_put_tiles(w, 1, (C.c_int * 1)(2), (C.c_int * 1)(0), ptrs, sizes) == -1
+    assert L.gcn10_tiff_finish(w, err, 512) != 0
