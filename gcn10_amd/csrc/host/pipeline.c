@@ -110,10 +110,11 @@ static void put_tiles_job(void *arg)
     struct put_job *j = arg;
     const uint32_t *tab = j->b->h_table + (size_t)j->raster * (size_t)j->across * (size_t)j->down * 2;
     const size_t n = (size_t)j->across * (size_t)j->down;
+    const bool arrived = j->w->run->gpu->event_sync(j->w->ctx, j->b->ev_d2h) == 0;  /* the strip's compressed bytes */
     int *txs = malloc(n * sizeof *txs), *tys = malloc(n * sizeof *tys);
     const void **data = malloc(n * sizeof *data);
     uint32_t *sizes = malloc(n * sizeof *sizes);
-    bool ok = txs && tys && data && sizes;
+    bool ok = arrived && txs && tys && data && sizes;
 
     for (int ty = 0; ok && ty < j->down; ty++) {
         for (int tx = 0; tx < j->across; tx++) {
@@ -209,8 +210,9 @@ static int drain_strip_inner(struct worker *w, struct strip_buf *b, gcn10_tiff_w
                 dst = b->h_spill;
             }
             b->h_tiles = dst;
+            /* the sink jobs wait for this copy themselves: the worker goes on to the next strip */
             if (g->memcpy_d2h(w->ctx, dst, b->d_arena, used, w->s_d2h) != 0 ||
-                g->event_record(w->ctx, b->ev_d2h, w->s_d2h) != 0 || g->event_sync(w->ctx, b->ev_d2h) != 0)
+                g->event_record(w->ctx, b->ev_d2h, w->s_d2h) != 0)
                 goto gpu_error;
         }
         for (int k = 0; k < GCN10_N_RASTERS; k++) {
