@@ -570,41 +570,35 @@ static int process_block(struct worker *w, int block_id)
                 g->stream_wait_event(w->ctx, w->s_kernel, b->ev_h2d) != 0)
                 goto gpu_fail;
         }
-        for (int k = 0; k < GCN10_N_RASTERS; k++)
-            outs[k] = b->d_out[k];
+        /* the strip's kernels on the compute stream */
         if (w->fused) {
             /* landcover + soil -> 18 x compressed tiles in one device pass, no CN strip in HBM */
-            int across = (W + TILE - 1) / TILE, down = (rows + TILE - 1) / TILE;
-
             if (g->deflate_fused_strip(w->ctx, d_esa, W, rows, w->d_cj + y0,
                                        GCN10_COND_DRAINED | GCN10_COND_UNDRAINED, 0x1ffu, b->d_arena,
-                                       b->arena_cap, b->d_table, b->d_cursor, w->s_kernel) != 0 ||
-                g->event_record(w->ctx, b->ev_kernel, w->s_kernel) != 0 ||
-                g->stream_wait_event(w->ctx, w->s_d2h, b->ev_kernel) != 0 ||
-                g->memcpy_d2h(w->ctx, b->h_cursor, b->d_cursor, 8, w->s_d2h) != 0 ||
-                g->memcpy_d2h(w->ctx, b->h_table, b->d_table,
-                              (size_t)across * down * GCN10_N_RASTERS * 8, w->s_d2h) != 0 ||
-                g->event_record(w->ctx, b->ev_meta, w->s_d2h) != 0)
+                                       b->arena_cap, b->d_table, b->d_cursor, w->s_kernel) != 0)
                 goto gpu_fail;
         }
-        else if (g->cn_strip(w->ctx, d_esa, W, rows, w->d_cj + y0,
-                             GCN10_COND_DRAINED | GCN10_COND_UNDRAINED, 0x1ffu, outs, w->s_kernel) != 0 ||
-                 g->event_record(w->ctx, b->ev_kernel, w->s_kernel) != 0 ||
-                 g->stream_wait_event(w->ctx, w->s_d2h, b->ev_kernel) != 0)
-            goto gpu_fail;
-        if (w->fused) {
-            /* issued above */
+        else {
+            for (int k = 0; k < GCN10_N_RASTERS; k++)
+                outs[k] = b->d_out[k];
+            if (g->cn_strip(w->ctx, d_esa, W, rows, w->d_cj + y0, GCN10_COND_DRAINED | GCN10_COND_UNDRAINED,
+                            0x1ffu, outs, w->s_kernel) != 0)
+                goto gpu_fail;
+            /* encode the 18 strips where they are */
+            if (r->gpu_deflate &&
+                g->deflate_strip(w->ctx, b->d_ptrs, GCN10_N_RASTERS, W, rows, b->d_arena, b->arena_cap,
+                                 b->d_table, b->d_cursor, w->s_kernel) != 0)
+                goto gpu_fail;
         }
-        else if (r->gpu_deflate) {
-            /* encode the 18 strips where they are; only sizes, offsets and (later, in
-             * drain_strip) the compressed bytes go to the host */
+        if (g->event_record(w->ctx, b->ev_kernel, w->s_kernel) != 0 ||
+            g->stream_wait_event(w->ctx, w->s_d2h, b->ev_kernel) != 0)
+            goto gpu_fail;
+        /* ... and what comes back on the copy stream */
+        if (r->gpu_deflate) {
+            /* sizes and offsets now; the compressed bytes when drain_strip knows how many */
             int across = (W + TILE - 1) / TILE, down = (rows + TILE - 1) / TILE;
 
-            if (g->deflate_strip(w->ctx, b->d_ptrs, GCN10_N_RASTERS, W, rows, b->d_arena, b->arena_cap,
-                                 b->d_table, b->d_cursor, w->s_kernel) != 0 ||
-                g->event_record(w->ctx, b->ev_kernel, w->s_kernel) != 0 ||
-                g->stream_wait_event(w->ctx, w->s_d2h, b->ev_kernel) != 0 ||
-                g->memcpy_d2h(w->ctx, b->h_cursor, b->d_cursor, 8, w->s_d2h) != 0 ||
+            if (g->memcpy_d2h(w->ctx, b->h_cursor, b->d_cursor, 8, w->s_d2h) != 0 ||
                 g->memcpy_d2h(w->ctx, b->h_table, b->d_table,
                               (size_t)across * down * GCN10_N_RASTERS * 8, w->s_d2h) != 0 ||
                 g->event_record(w->ctx, b->ev_meta, w->s_d2h) != 0)
