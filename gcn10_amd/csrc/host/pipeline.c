@@ -298,6 +298,7 @@ static void free_strip_buffers(struct worker *w)
         b->h_cursor = b->d_cursor = NULL;
         b->d_ptrs = NULL;
         b->h_esa = b->d_esa = NULL;
+        b->esa_px = 0;
     }
     w->buf_px = 0;
     w->buf_tiles = 0;
@@ -316,8 +317,7 @@ static int ensure_strip_buffers(struct worker *w, int W)
     for (int i = 0; i < w->run->nbuf; i++) {
         struct strip_buf *b = &w->buf[i];
 
-        GPU_TRY(w, g->host_alloc(w->ctx, px, (void **)&b->h_esa));
-        GPU_TRY(w, g->malloc(w->ctx, px, (void **)&b->d_esa));
+        /* (landcover staging h_esa / d_esa: only when a block goes through the host reader) */
         for (int k = 0; k < GCN10_N_RASTERS; k++) {
             if (!w->run->gpu_deflate)
                 GPU_TRY(w, g->host_alloc(w->ctx, px, (void **)&b->h_out[k]));
@@ -549,12 +549,24 @@ static int process_block(struct worker *w, int block_id)
         }
         wait_sink(b);
 
-        const uint8_t *d_esa = inflated ? w->d_block + (size_t)y0 * (size_t)W : b->d_esa;
+        const uint8_t *d_esa = inflated ? w->d_block + (size_t)y0 * (size_t)W : b->d_esa;   /* (set below if not yet) */
 
         if (!inflated) {
             /* landcover rows straight into the pinned strip (replaces the malloc +
              * GDALRasterIO of src/raster.c:169-178) */
             double t_r0 = now_seconds();
+
+            if (!b->h_esa || b->esa_px < w->buf_px) {
+                if (b->h_esa) g->host_free(w->ctx, b->h_esa);
+                if (b->d_esa) g->free(w->ctx, b->d_esa);
+                b->h_esa = b->d_esa = NULL;
+                b->esa_px = 0;
+                if (g->host_alloc(w->ctx, w->buf_px, (void **)&b->h_esa) != 0 ||
+                    g->malloc(w->ctx, w->buf_px, (void **)&b->d_esa) != 0)
+                    goto gpu_fail;
+                b->esa_px = w->buf_px;
+                d_esa = b->d_esa;
+            }
             /* the strip's landcover tiles are decoded concurrently on the I/O pool */
             int read_rc = gcn10_raster_read_mt(w->esa, xoff, yoff + y0, W, rows, b->h_esa, r->pool, err,
                                                sizeof err);

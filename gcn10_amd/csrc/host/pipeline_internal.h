@@ -18,8 +18,9 @@ struct run;
 
 /* one rotating set of strip buffers */
 struct strip_buf {
-    uint8_t *h_esa;                         /* pinned */
+    uint8_t *h_esa;                         /* pinned; these two only for blocks read on the host */
     uint8_t *d_esa;
+    size_t esa_px;                          /* their capacity */
     uint8_t *h_out[GCN10_N_RASTERS];        /* pinned */
     uint8_t *d_out[GCN10_N_RASTERS];
     gcn10_event_t ev_h2d, ev_kernel, ev_d2h, ev_meta;
