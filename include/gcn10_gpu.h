@@ -193,7 +193,9 @@ int gcn10_gpu_deflate_strip(gcn10_gpu_ctx *ctx, const uint8_t *const *rasters_de
  * (src/cn.c:236-290 and the zlib of src/raster.c:204-219 in one device pass; no CN raster
  * is written to or read from HBM).  Stream r' of the table is the r'-th selected raster in
  * ascending raster order (cond*9 + hc*3 + arc).  Needs the tables to define at most 256
- * distinct 18-vectors (GCN10_E_STATE otherwise; the shipped tables define about 110). */
+ * distinct 18-vectors (GCN10_E_STATE otherwise; the shipped tables define about 110).
+ * Two table entries may name the same arena bytes: where no dual soil class lies under a tile,
+ * the drained and the undrained raster of a table are the same stream, emitted once. */
 int gcn10_gpu_deflate_fused_available(gcn10_gpu_ctx *ctx);     /* 1 after set_tables if <= 256 classes */
 int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, int rows,
                                   const int32_t *cj, unsigned cond_mask, unsigned table_mask,
@@ -203,12 +205,13 @@ int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W,
 /* Landcover input decode on the GPU (replaces the inflate GDALRasterIO does on the host inside
  * load_raster, /root/reference/src/raster.c:167-176).  `tiles_dev` describes n_tiles zlib
  * streams (TIFF Compression 8 / 32946: one per tile or strip of the landcover files) lying in
- * `comp_dev`; every stream is decoded by one wavefront into a linear slot of at most
- * chunk_bytes, and the wanted window of each chunk (copy_w x copy_h pixels from (src_x, src_y)
+ * `comp_dev`; every stream is decoded by one workgroup (a decoder and a copier wavefront) into
+ * a linear slot of at most chunk_bytes, and the wanted window of each chunk (copy_w x copy_h pixels from (src_x, src_y)
  * of a chunk chunk_w pixels wide) is copied to dst_dev + dst_off, rows dst_stride apart.
  * status_dev[i] = 0, or the reason stream i is not a valid zlib stream (GCN10_INFLATE_E_*); a
  * stream that ends early leaves zeros, one that is longer than out_len is cut there, as the
- * host reader (tiff.c) does.  Streams must start at multiples of 16 bytes in comp_dev. */
+ * host reader (tiff.c) does.  Streams must start at multiples of 16 bytes in comp_dev, and
+ * comp_dev must be readable up to the next multiple of 4 past every stream's end. */
 typedef struct gcn10_inflate_tile {
     uint64_t in_off;        /* byte offset of the zlib stream in comp_dev, multiple of 16 */
     uint32_t in_len;        /* its size in bytes */
@@ -232,7 +235,8 @@ int gcn10_gpu_inflate_tiles(gcn10_gpu_ctx *ctx, const uint8_t *comp_dev,
 /* Launch-shape knobs of the strip kernels, for tuning runs; results never
  * depend on them.  Names: "grid_blocks_per_cu" (1..64), "ilp16" (0 = by raster count | 1 | 2),
  * "ilp1" (1|2|4), "nontemporal" (0|1), "xcd_slabs" (0|1), "prefetch" (-1 = per-kernel default | 0 | 1), "deflate_wave_codes" (0|1: code
- * construction of the tile encoder by one thread or one wave per tile). */
+ * construction of the tile encoder by one thread or one wave per tile), "fused_diag" (timing
+ * experiments on the fused encoder; nonzero values produce invalid streams). */
 int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value);
 
 /* Measurement: the next gcn10_gpu_cn_strip launch records `start` / `stop` as part of
