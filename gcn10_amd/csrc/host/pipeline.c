@@ -888,6 +888,8 @@ static void *worker_main(void *arg)
             continue;
         }
         t0 = now_seconds();
+        if (w->t_first_block == 0.0)
+            w->t_first_block = t0;
         if (process_block(w, id) != 0) {
             atomic_store(&r->fatal, 1);     /* where the reference calls MPI_Abort */
             break;
@@ -1146,7 +1148,7 @@ int gcn10_run(const gcn10_run_options *opt)
     gcn10_log_message(log0, "INFO", msg, true);
     {
         int done_blocks = 0;
-        double busy = 0, rd = 0, gw = 0, sw = 0, so = 0, cr = 0, fi = 0, dv = 0;
+        double busy = 0, rd = 0, gw = 0, sw = 0, so = 0, cr = 0, fi = 0, dv = 0, steady = 0;
 
         for (int i = 0; i < r->n_workers; i++) {
             done_blocks += r->workers[i].blocks_done;
@@ -1159,10 +1161,20 @@ int gcn10_run(const gcn10_run_options *opt)
             fi += r->workers[i].t_finish;
             dv += r->workers[i].t_device;
         }
-        snprintf(msg, sizeof msg, "timing: %d blocks, %.3f s wall, %d gpu worker(s)%s%s%s; worker seconds: "
+        {
+            /* from the moment the first worker had its GPU, buffers and files ready: what a long
+             * run sees per block */
+            double first = 0.0;
+
+            for (int i = 0; i < r->n_workers; i++)
+                if (r->workers[i].t_first_block > 0.0 && (first == 0.0 || r->workers[i].t_first_block < first))
+                    first = r->workers[i].t_first_block;
+            steady = first > 0.0 ? now_seconds() - first : 0.0;
+        }
+        snprintf(msg, sizeof msg, "timing: %d blocks, %.3f s wall (%.3f s after start-up), %d gpu worker(s)%s%s%s; worker seconds: "
                  "in blocks %.3f, reading landcover %.3f, waiting for gpu %.3f, waiting for sink %.3f, "
                  "soil window %.3f, creating outputs %.3f, finishing outputs %.3f, device setup %.3f",
-                 done_blocks, now_seconds() - t_start, r->n_workers, r->null_sink ? ", null sink" : "",
+                 done_blocks, now_seconds() - t_start, steady, r->n_workers, r->null_sink ? ", null sink" : "",
                  r->gpu_deflate ? (r->fused ? ", fused gpu deflate" : ", gpu deflate") : ", host zlib",
                  r->gpu_inflate ? ", gpu inflate of deflate landcover" : "", busy, rd, gw, sw, so, cr, fi, dv);
         gcn10_log_message(log0, "INFO", msg, false);

@@ -77,6 +77,7 @@ struct worker {
     size_t n_inflate;                       /* chunks of the block in flight */
     int blocks_done;
     double busy_seconds;
+    double t_first_block;                   /* when this worker started its first block */
     double t_read, t_gpu_wait, t_sink_wait;            /* where the worker thread's time goes */
     double t_soil, t_create, t_finish, t_device;
 };

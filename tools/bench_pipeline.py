@@ -108,9 +108,10 @@ def run_modes(a, wd, size, nb, build_s):
                              cwd=wd, env=env, capture_output=True, text=True)
         wall = time.time() - t0
         log = open(os.path.join(wd, "logs", "rank_0.log")).read() if os.path.exists(os.path.join(wd, "logs", "rank_0.log")) else ""
-        m = re.search(r"timing: (\d+) blocks, ([0-9.]+) s wall", log)
+        m = re.search(r"timing: (\d+) blocks, ([0-9.]+) s wall(?: \(([0-9.]+) s after start-up\))?", log)
         done = int(m.group(1)) if m else 0
         secs = float(m.group(2)) if m else wall
+        steady = float(m.group(3)) if m and m.group(3) else None
         nbytes = 0
         for d in ("cn_rasters_drained", "cn_rasters_undrained"):
             p = os.path.join(wd, d)
@@ -120,6 +121,9 @@ def run_modes(a, wd, size, nb, build_s):
         res["modes"][mode] = {"rc": out.returncode, "worker_seconds": mt.group(1) if mt else None, "blocks_done": done, "seconds": round(secs, 3),
                               "cn_gpx_per_s": round(done * size * size * 18 / secs / 1e9, 3) if secs else None,
                               "seconds_per_block": round(secs / done, 3) if done else None,
+                              "seconds_after_startup": steady,
+                              "steady_seconds_per_block": round(steady / done, 4) if done and steady else None,
+                              "steady_cn_gpx_per_s": round(done * size * size * 18 / steady / 1e9, 1) if steady else None,
                               "output_bytes": nbytes, "stderr_tail": out.stderr[-300:] if out.returncode else ""}
     print(json.dumps(res))
     for d in ("cn_rasters_drained", "cn_rasters_undrained", "logs"):

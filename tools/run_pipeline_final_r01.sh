@@ -7,4 +7,4 @@ timeout -k 10 900 python tools/bench_pipeline.py --pattern natural --blocks 16 -
 timeout -k 10 900 python tools/bench_pipeline.py --pattern patches --blocks 16 --modes files,null --esa-compression 1 > gpurun_out/final_patches_raw16.json
 for f in final_patches_deflate32 final_natural_deflate16 final_patches_raw16; do python3 -c "
 import json; d=json.load(open('gpurun_out/$f.json'))
-for k,m in d['modes'].items(): print('$f', k, m['seconds'], m['seconds_per_block'], m['cn_gpx_per_s'], m['output_bytes'])"; done
+for k,m in d['modes'].items(): print('$f', k, m['seconds'], m['seconds_per_block'], m['cn_gpx_per_s'], '| after start-up:', m['seconds_after_startup'], m['steady_seconds_per_block'], m['steady_cn_gpx_per_s'])"; done
