@@ -230,6 +230,7 @@ struct SharedFA {
             uint32_t H[kGroup][256];                    // literal counts by VALUE, kGroup rasters at a time
             uint32_t s1[GCN10_N_RASTERS], s2[GCN10_N_RASTERS];
             uint32_t row_base[4];
+            uint32_t sig[GCN10_N_RASTERS], cand[GCN10_N_RASTERS], differ;
         } a;
     };
 };
@@ -328,42 +329,62 @@ __global__ __launch_bounds__(kTile) void fused_stats_kernel(const FusedJob job)
     }
     __syncthreads();
 
-    // Adler-32 of every raster's tile: thread t = class t, s1 = 1 + sum n_c val, s2 = N + sum w_c val
+    // Adler-32 of every raster's tile: thread t = class t, s1 = 1 + sum n_c val, s2 = N + sum w_c val;
+    // and a hash of (class, value) over the classes that occur, per raster (alias detection below)
     const uint32_t lits = sh.a.lit_hist[t];
     {
         const uint32_t n = sh.a.n_c[t];
         const uint32_t w = sh.a.w_c[t] % 65521u;
+        const bool present = n != 0;
+        if (t < GCN10_N_RASTERS)
+            sh.a.sig[t] = 0;
+        if (t == 0)
+            sh.a.differ = 0;
+        __syncthreads();
         for (uint32_t j = 0; j < job.n_sel; j++) {
             const uint32_t v = class_val[job.sel[j] * 256 + t];
-            const uint32_t p1 = wave_sum64(n * v);              // <= 2^24 in all
-            const uint32_t p2 = wave_sum64(w * v);              // <= 256 * 65520 * 255 < 2^32 in all
+            uint32_t h = present ? (((uint32_t)t * 0x9E3779B1u + v * 0x85EBCA6Bu + 0x27D4EB2Fu) * 0x165667B1u) : 0u;
+            h ^= h >> 15;
+            const uint32_t p1 = wave_sum64(n * v), p2 = wave_sum64(w * v), p3 = wave_sum64(h);
             if ((t & 63) == 0) {
                 atomicAdd(&sh.a.s1[j], p1);
                 atomicAdd(&sh.a.s2[j], p2);
+                atomicAdd(&sh.a.sig[j], p3);
             }
         }
     }
-    // Rasters that cannot differ on this tile: the drained and the undrained raster of a table
-    // map every class that OCCURS here to the same value wherever no dual soil class (A/D .. D/D)
-    // lies under the tile -- most of the world.  The later one becomes an alias of the earlier:
-    // no code construction, no emission, its table entry points at the same bytes.
+    // Rasters that cannot differ on this tile: two selected rasters whose tables map every class
+    // that OCCURS here to the same value are the same bytes on it (a table's drained and undrained
+    // raster wherever no dual soil class lies under the tile; all 18 on open water, ice, no-data).
+    // The later raster becomes an alias of the earliest equal one.  The hash proposes the partner,
+    // a comparison class by class confirms it.
     uint32_t alias_of[GCN10_N_RASTERS];
     {
         const bool present = sh.a.n_c[t] != 0;
+        __syncthreads();
+        if ((uint32_t)t < job.n_sel) {
+            uint32_t cand = 0xffu;
+            for (uint32_t q = 0; q < (uint32_t)t; q++)
+                if (cand == 0xffu && sh.a.sig[q] == sh.a.sig[t])
+                    cand = q;
+            sh.a.cand[t] = cand;
+        }
+        __syncthreads();
+        {
+            uint32_t mine = 0;
+            if (present)
+                for (uint32_t j = 1; j < job.n_sel; j++) {
+                    const uint32_t q = sh.a.cand[j];
+                    if (q != 0xffu && class_val[job.sel[j] * 256 + t] != class_val[job.sel[q] * 256 + t])
+                        mine |= 1u << j;
+                }
+            if (mine)
+                atomicOr(&sh.a.differ, mine);
+        }
+        __syncthreads();
         for (uint32_t j = 0; j < job.n_sel; j++) {
-            alias_of[j] = 0;
-            const uint32_t r = job.sel[j];
-            if (r < 9u)
-                continue;
-            uint32_t jp = 0xffffffffu;
-            for (uint32_t q = 0; q < j; q++)
-                if (job.sel[q] == r - 9u)
-                    jp = q;
-            if (jp == 0xffffffffu)
-                continue;                           // (uniform: sel[] is a kernel argument)
-            const int differs = present && class_val[r * 256 + t] != class_val[(r - 9u) * 256 + t];
-            if (!__syncthreads_or(differs))
-                alias_of[j] = kAliasFlag | jp;
+            const uint32_t q = sh.a.cand[j];
+            alias_of[j] = (q != 0xffu && !((sh.a.differ >> j) & 1u)) ? (kAliasFlag | q) : 0u;
         }
     }
     // per raster: literal counts by VALUE, kGroup rasters per round

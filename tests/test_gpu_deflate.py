@@ -235,6 +235,37 @@ def test_fused_encoder_shares_streams_where_drained_equals_undrained(engine, tab
                     assert int(table[r, ty, tx, 0]) != int(table[r - 9, ty, tx, 0])
 
 
+def test_fused_encoder_emits_one_stream_where_all_rasters_agree(engine, tables):
+    """Open water (class 80: CN 100 in every table), snow and ice (70: 0), no-data (0: 255): on a
+    tile that holds nothing else all 18 rasters are the same bytes -- one stream, 18 table entries."""
+    from gcn10_amd import host
+    from oracle import cn_oracle_c as oc
+    H, W = 256, 1024
+    esa = np.zeros((H, W), np.uint8)
+    esa[:, :256] = 80
+    esa[:, 256:512] = 70
+    esa[:128, 512:768] = 80                              # water and no-data: still one stream
+    esa[:, 768:] = np.where(np.arange(256)[None, :] < 128, 80, 40)     # water and cropland: rasters differ
+    coarse = np.full((12, 42), 2, np.uint8)              # soil group B everywhere
+    gt = [0.0, 0.001, 0.0, 1.0, 0.0, -0.001]
+    sgt = [0.0, 0.025, 0.0, 1.0, 0.0, -0.025]
+    ci, cj = host.build_index_maps(gt, sgt, W, H, 42, 12)
+    engine.set_tables(tables)
+    bufs = [engine.upload(a) for a in (esa, coarse, ci, cj)]
+    engine.prepare_tile(bufs[1].ptr, 42, 12, bufs[2].ptr, W)
+    data, table, used = engine.deflate_fused(bufs[0].ptr, W, H, bufs[3].ptr)
+    for b in bufs:
+        b.close()
+    want = oc.process_block_mem(esa, gt, coarse, sgt, tables)
+    for r in range(18):
+        for tx in range(4):
+            off, size = int(table[r, 0, tx, 0]), int(table[r, 0, tx, 1])
+            assert zlib.decompress(data[off:off + size].tobytes()) == want[r][:, tx * 256:(tx + 1) * 256].tobytes()
+    for tx in range(3):
+        assert len({int(table[r, 0, tx, 0]) for r in range(18)}) == 1, tx
+    assert len({int(table[r, 0, 3, 0]) for r in range(18)}) > 1
+
+
 def test_fused_vs_unfused_size(engine, tables):
     """The class-based match structure costs little compression against per-raster parsing."""
     H, W = 512, 768
