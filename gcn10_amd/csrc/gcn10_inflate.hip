@@ -707,80 +707,85 @@ __device__ __forceinline__ uint32_t decode_batch(Shared &sh, Decoder &d, uint32_
             }
             continue;
         }
-        // ---- kInSymbols: one window of 64 candidate start bits at d.P ----
+        // ---- kInSymbols: one window of 128 candidate start bits at d.P, two per lane ----
         const uint32_t q0 = d.P >> 5;
         ensure_piece(r, q0 >> 6);
-        uint32_t D0, D1, D2, D3, D4;
-        if ((q0 & 63u) <= 59u) {
-            // the usual case: all five dwords in one piece, one select for all of them
+        uint32_t D[7];
+        if ((q0 & 63u) <= 57u) {
+            // the usual case: all seven dwords in one piece, one select for all of them
             const uint32_t piece = (q0 >> 6) == r.chunk ? r.cur : r.prv;
             const int l0 = (int)(q0 & 63u);
-            D0 = (uint32_t)__builtin_amdgcn_readlane((int)piece, l0);
-            D1 = (uint32_t)__builtin_amdgcn_readlane((int)piece, l0 + 1);
-            D2 = (uint32_t)__builtin_amdgcn_readlane((int)piece, l0 + 2);
-            D3 = (uint32_t)__builtin_amdgcn_readlane((int)piece, l0 + 3);
-            D4 = (uint32_t)__builtin_amdgcn_readlane((int)piece, l0 + 4);
+#pragma unroll
+            for (int i = 0; i < 7; i++)
+                D[i] = (uint32_t)__builtin_amdgcn_readlane((int)piece, l0 + i);
         }
         else {
-            D0 = stream_dword(r, q0);
-            D1 = stream_dword(r, q0 + 1);
-            D2 = stream_dword(r, q0 + 2);
-            D3 = stream_dword(r, q0 + 3);
-            D4 = stream_dword(r, q0 + 4);
+#pragma unroll
+            for (int i = 0; i < 7; i++)
+                D[i] = stream_dword(r, q0 + (uint32_t)i);
         }
         const uint32_t rel = (d.P & 31u) + (uint32_t)lane;          // < 95
         const uint32_t o = rel >> 5, sft = rel & 31u;
-        const uint32_t a = o == 0 ? D0 : o == 1 ? D1 : D2;
-        const uint32_t b = o == 0 ? D1 : o == 1 ? D2 : D3;
-        const uint32_t c = o == 0 ? D2 : o == 1 ? D3 : D4;
-        const uint32_t lo = __builtin_amdgcn_alignbit(b, a, sft);   // bits P+lane .. +31
-        const uint32_t hi = __builtin_amdgcn_alignbit(c, b, sft);   //          +32 .. +63
-        const uint32_t e1 = sh.lit_tab[lo & ((1u << kLitRoot) - 1u)];
-        const uint32_t cl = e1 & 15u, kind = (e1 >> 4) & 3u;
-        uint32_t bits = cl, outl = (e1 >> 6) & 3u;
-        uint32_t tok = outl << 24 | (e1 >> 8);
-        uint32_t special = e1 == 0 ? 2u : (kind == (uint32_t)kEndOfBlock ? 1u : 0u);
-        {
-            // as if it were a match (harmless where it is not: the lookups stay in the tables)
-            const uint32_t eb = (e1 >> 6) & 7u;
-            const uint32_t len = ((e1 >> 9) & 511u) + ((lo >> cl) & ((1u << eb) - 1u));
-            const uint32_t t = cl + eb;                             // <= 20
-            const uint32_t x2 = __builtin_amdgcn_alignbit(hi, lo, t);
-            const uint32_t de = sh.dist_tab[x2 & ((1u << kDistRoot) - 1u)];
-            const uint32_t dl = de & 15u, deb = (de >> 4) & 15u;
-            const uint32_t dist = ((de >> 8) & 0xffffu) + ((x2 >> dl) & ((1u << deb) - 1u));
-            if (kind == (uint32_t)kLength && e1 != 0) {
-                bits = t + dl + deb;                                // <= 48
-                outl = len;
-                tok = kTokMatch | ((len - 3u) & 255u) << 16 | ((dist - 1u) & 0xffffu);
-                if (de == 0)
-                    special = 2u;
+        uint32_t info[2], tok[2];
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            // candidate at bit lane + 64 * half: dwords o + 2 * half .. + 2 of the seven
+            const uint32_t a = o == 0 ? D[2 * half] : o == 1 ? D[2 * half + 1] : D[2 * half + 2];
+            const uint32_t b = o == 0 ? D[2 * half + 1] : o == 1 ? D[2 * half + 2] : D[2 * half + 3];
+            const uint32_t c = o == 0 ? D[2 * half + 2] : o == 1 ? D[2 * half + 3] : D[2 * half + 4];
+            const uint32_t lo = __builtin_amdgcn_alignbit(b, a, sft);   // bits of the candidate .. +31
+            const uint32_t hi = __builtin_amdgcn_alignbit(c, b, sft);   //                     +32 .. +63
+            const uint32_t e1 = sh.lit_tab[lo & ((1u << kLitRoot) - 1u)];
+            const uint32_t cl = e1 & 15u, kind = (e1 >> 4) & 3u;
+            uint32_t bits = cl, outl = (e1 >> 6) & 3u;
+            uint32_t tk = outl << 24 | (e1 >> 8);
+            uint32_t special = e1 == 0 ? 2u : (kind == (uint32_t)kEndOfBlock ? 1u : 0u);
+            {
+                // as if it were a match (harmless where it is not: the lookups stay in the tables)
+                const uint32_t eb = (e1 >> 6) & 7u;
+                const uint32_t len = ((e1 >> 9) & 511u) + ((lo >> cl) & ((1u << eb) - 1u));
+                const uint32_t t = cl + eb;                             // <= 20
+                const uint32_t x2 = __builtin_amdgcn_alignbit(hi, lo, t);
+                const uint32_t de = sh.dist_tab[x2 & ((1u << kDistRoot) - 1u)];
+                const uint32_t dl = de & 15u, deb = (de >> 4) & 15u;
+                const uint32_t dist = ((de >> 8) & 0xffffu) + ((x2 >> dl) & ((1u << deb) - 1u));
+                if (kind == (uint32_t)kLength && e1 != 0) {
+                    bits = t + dl + deb;                                // <= 48
+                    outl = len;
+                    tk = kTokMatch | ((len - 3u) & 255u) << 16 | ((dist - 1u) & 0xffffu);
+                    if (de == 0)
+                        special = 2u;
+                }
             }
+            // bits | bytes produced << 6 for a token the walk passes; reason << 15 for one it stops
+            // at: an end of block (with its bits, which the walk takes) or a code the tables do not
+            // hold (no bits: the scalar reader starts at it)
+            info[half] = special == 2u ? 2u << 15 : special == 1u ? (cl | 1u << 15) : (bits | outl << 6);
+            tok[half] = tk;
         }
-        // bits | bytes produced << 6 for a token the walk passes; reason << 15 for one it stops at:
-        // an end of block (with its bits, which the walk takes) or a code the tables do not hold
-        // (no bits: the scalar reader starts at it)
-        const uint32_t info = special == 2u ? 2u << 15 : special == 1u ? (cl | 1u << 15) : (bits | outl << 6);
         // ---- the chain: from bit 0 of the window, token by token.  One exit, no branches in the
         // body: the loop is the serial core of the decoder ----
         uint32_t k = 0, n_new = 0, src = 0, stop = 0;
         const uint32_t room = (uint32_t)kBatch - n;
         bool go = true;
         while (go) {
-            const uint32_t inf = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)k);
+            const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane((int)info[0], (int)(k & 63u));
+            const uint32_t i1 = (uint32_t)__builtin_amdgcn_readlane((int)info[1], (int)(k & 63u));
+            const uint32_t inf = k < 64u ? i0 : i1;
             src = (uint32_t)lane == n_new ? k : src;    // (a stop token's entry lies beyond n_new: unused)
             n_new += inf < 0x8000u ? 1u : 0u;
             d.pos += (inf >> 6) & 511u;
             k += inf & 63u;
             stop = inf >> 15;
-            go = (stop == 0u) & (d.pos < d.limit) & (n_new < room) & (k < 64u);
+            go = (stop == 0u) & (d.pos < d.limit) & (n_new < room) & (k < 128u);
         }
         if (stop == 0u && d.pos >= d.limit)
             stop = 4u;
         {
-            const uint32_t mine = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)tok);
+            const uint32_t m0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src & 63u) << 2), (int)tok[0]);
+            const uint32_t m1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src & 63u) << 2), (int)tok[1]);
             if ((uint32_t)lane < n_new)
-                ring[n + (uint32_t)lane] = mine;
+                ring[n + (uint32_t)lane] = src < 64u ? m0 : m1;
             n += n_new;
         }
         d.P += k;
