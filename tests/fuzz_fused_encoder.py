@@ -46,6 +46,7 @@ def main():
     shipped = np.stack([oc.load_lookup_table(os.path.join(LOOKUPS, "default_lookup_%s_%s.csv" % (hc, arc)))[0]
                         for hc in onp.HCS for arc in onp.ARCS])
     t_end = time.time() + a.seconds
+    t_print = time.time()
     cases = tiles_checked = 0
     with gpu.Engine(0) as e:
         while time.time() < t_end:
@@ -94,6 +95,9 @@ def main():
                             sys.exit(1)
                         tiles_checked += 1
             cases += 1
+            if time.time() - t_print > 60:
+                t_print = time.time()
+                print("... %d cases, %d streams so far, no difference" % (cases, tiles_checked), flush=True)
     print("cases %d, streams checked %d, differences 0" % (cases, tiles_checked))
 
 

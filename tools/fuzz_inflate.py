@@ -88,6 +88,7 @@ def main():
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     t_end = time.time() + a.seconds
+    t_print = time.time()
     n_ok = n_refused = n_streams = 0
     bad = []
     with gpu.Engine(0) as e:
@@ -140,6 +141,9 @@ def main():
                         n_ok += 1
             if bad:
                 break
+            if time.time() - t_print > 60:
+                t_print = time.time()
+                print("... %d streams so far, no difference" % n_streams, flush=True)
     print("streams %d, decoded like zlib %d, refused %d, differences %d %s" % (n_streams, n_ok, n_refused, len(bad), bad[:5]))
     sys.exit(1 if bad else 0)
 
