@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--gpu-deflate", type=int, default=2)
     ap.add_argument("--workers-per-gpu", type=int, default=0)
     ap.add_argument("--gpu-inflate", type=int, default=1)
+    ap.add_argument("--repeat", type=int, default=1,
+                    help="list every block geometry this many times under different ids (long runs on a small world)")
     ap.add_argument("--dual-soil-fraction", type=float, default=-1.0,
                     help="fraction of the soil cells that keep a dual class (11..14); the others become 1..4. "
                          "Default: the bench distribution (40 %% dual), unlike most of the real world")
@@ -92,7 +94,8 @@ def build_world(a, wd, size, nb, px):
     tiffutil.write_tiff(os.path.join(wd, "soil.tif"), soil, gt=[0.0, 3.0 / hs, 0.0, 3.0, 0.0, -3.0 / hs],
                         compression=8, rows_per_strip=64)
     tiffutil.write_block_shapefile(os.path.join(wd, "blocks"),
-                                   [(i + 1, 3.0 * i, 0.0, 3.0 * (i + 1), 3.0) for i in range(nb)])
+                                   [(rep * nb + i + 1, 3.0 * i, 0.0, 3.0 * (i + 1), 3.0)
+                                    for rep in range(a.repeat) for i in range(nb)])
 
 
 def run_modes(a, wd, size, nb, build_s):
