@@ -401,6 +401,22 @@ __device__ __forceinline__ void copy_match(Shared &sh, Output &o, uint32_t len, 
         if ((uint32_t)lane < len)
             sh.window[(o.pos + (uint32_t)lane) & kWindowMask] = sh.window[(from + (uint32_t)lane) & kWindowMask];
     }
+    else if (dist >= len) {
+        // source and destination apart, up to 258 bytes: all the reads first, then all the writes
+        // (one LDS round trip instead of five)
+        uint8_t v[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const uint32_t k = (uint32_t)lane + 64u * (uint32_t)i;
+            v[i] = k < len ? sh.window[(from + k) & kWindowMask] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const uint32_t k = (uint32_t)lane + 64u * (uint32_t)i;
+            if (k < len)
+                sh.window[(o.pos + k) & kWindowMask] = v[i];
+        }
+    }
     else if (dist >= 64u) {
         // 64 bytes per step; a later step may read what an earlier one wrote (LDS keeps order)
         for (uint32_t base = 0; base < len; base += 64u) {
