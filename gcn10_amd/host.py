@@ -102,7 +102,7 @@ def parse_config(path: str) -> dict:
     err = C.create_string_buffer(1024)
     rc = lib().gcn10_config_parse(os.fsencode(path), C.byref(cfg), err, 1024)
     if rc != 0:
-        raise HostError(err.value.decode())
+        raise HostError(err.value.decode(errors="replace"))
     out = {}
     for name, _t in Config._fields_:
         v = getattr(cfg, name)
@@ -140,7 +140,7 @@ def read_blocks_shapefile(path: str):
     b = Blocks()
     err = C.create_string_buffer(1024)
     if lib().gcn10_blocks_open(os.fsencode(path), C.byref(b), err, 1024) != 0:
-        raise HostError(err.value.decode())
+        raise HostError(err.value.decode(errors="replace"))
     ids = [b.id[i] for i in range(b.n)]
     bbox = np.array([list(b.bbox[i]) for i in range(b.n)], dtype=np.float64).reshape(b.n, 4)
     lib().gcn10_blocks_free(C.byref(b))
@@ -169,7 +169,7 @@ class Raster:
         self._h = lib().gcn10_raster_open(os.fsencode(path),
                                           os.fsencode(tile_dir) if tile_dir else None, err, 1024)
         if not self._h:
-            raise HostError(err.value.decode())
+            raise HostError(err.value.decode(errors="replace"))
         xs, ys = C.c_int(), C.c_int()
         gt = np.empty(6, dtype=np.float64)
         lib().gcn10_raster_info(self._h, C.byref(xs), C.byref(ys), gt)
@@ -179,7 +179,7 @@ class Raster:
         out = np.empty((ycount, xcount), dtype=np.uint8)
         err = C.create_string_buffer(1024)
         if lib().gcn10_raster_read(self._h, xoff, yoff, xcount, ycount, out.ctypes.data, err, 1024) != 0:
-            raise HostError(err.value.decode())
+            raise HostError(err.value.decode(errors="replace"))
         return out
 
     def georef_ptr(self):
@@ -200,7 +200,7 @@ class Raster:
         L.gcn10_read_plan_free.restype = None
         rc = L.gcn10_raster_plan_window(self._h, xoff, yoff, xcount, ycount, C.byref(plan), err, 1024)
         if rc < 0:
-            raise HostError(err.value.decode())
+            raise HostError(err.value.decode(errors="replace"))
         if rc > 0:
             return None
         try:
@@ -233,7 +233,7 @@ def save_raster(data: np.ndarray, gt, path: str, georef_ptr=None, level: int = 0
     rc = lib().gcn10_save_raster(a.ctypes.data, a.shape[1], a.shape[0], _f(gt, 6), georef_ptr,
                                  os.fsencode(path), level, err, 1024)
     if rc != 0:
-        raise HostError(err.value.decode())
+        raise HostError(err.value.decode(errors="replace"))
 
 
 def _f(v, n):
