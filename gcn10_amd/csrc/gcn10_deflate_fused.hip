@@ -533,7 +533,7 @@ __global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
     }
     for (int i = t; i < 4 * kGroup * kStageWords; i += kTile)
         (&sh.c.stage[0][0][0])[i] = 0u;
-    __threadfence();                                // the zeroed slots are in place before anything is OR-ed into them
+    __threadfence_block();                          // the zeroed slots are in place before this workgroup ORs into them
     __syncthreads();
 
     if (coded && !(job.diag & 2u)) {
