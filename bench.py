@@ -17,16 +17,24 @@ Workloads (BASELINE.json `configs`):
   config4                  all 9 lookups x {drained, undrained} fused: 18 rasters (19.0016 B/px)
   config4-drained          9 rasters of one drainage condition (10.0016 B/px)
 
-value = CN Gpixels/s = block pixels x CN rasters produced x N / elapsed (max over ranks);
-at N > 1 every rank owns its own block (weak scaling, no data-path collective).
+value = CN Gpixels/s = block pixels x CN rasters produced x N / whole-job time, where the
+whole-job time runs from the first rank's start to the last rank's end (CLOCK_MONOTONIC is
+common to the processes of one node).  At N > 1 every rank owns its own block on its own GPU
+(weak scaling): the path has no collective (src/main.c:171 -- independent ranks, one barrier),
+so ranks meet only at a barrier before and after the timed steps, through files
+(gcn10_amd/shard.py) -- no RCCL, no torch.  `python bench.py --gpus N` without a launcher starts
+the N rank processes itself, before anything touches a GPU.
 """
 from __future__ import annotations
 
 import argparse
+import importlib
 import json
 import os
+import shutil
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -89,28 +97,31 @@ def synth_block(seed: int, size: int, pattern: str):
 
 def cpu_baseline(workload: str, size: int):
     """Reference-shaped oracle on this box's host cores; separate process tree, before
-    this process touches the GPU."""
+    this process touches the GPU.  SURVEY.md 8(d): P = 1 and P = all physical cores (plus the
+    one-GPU box's 16-core share), and the fused -march=native pass as a "best CPU" line."""
     cond_mask, table_mask, _ = WORKLOADS[workload]
     n_out = bin(cond_mask).count("1") * bin(table_mask).count("1")
-    # about 10-30 s of CPU work per worker: 16000 rows for one raster, 2000 rows for all 18
-    rows = max(16, min(size, (16000 if n_out == 1 else 36000 // n_out)))
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--width", str(size),
-           "--rows", str(rows), "--cond-mask", str(cond_mask), "--table-mask", str(table_mask)]
+           "--cond-mask", str(cond_mask), "--table-mask", str(table_mask)]
     try:
         out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=900).stdout
         r = json.loads(out.strip().splitlines()[-1])
     except Exception as exc:  # the baseline is a reported extra, never a reason to lose the bench line
         return {"value": None, "unit": "CN Gpx/s", "cores": 0, "kind": "port", "sample": "failed: %s" % exc}
+    head = r["headline"]
     return {
-        "value": round(r["multi"]["gpx_per_s"], 4), "unit": "CN Gpx/s", "cores": r["multi"]["procs"],
+        "value": round(head["gpx_per_s"], 4), "unit": "CN Gpx/s", "cores": head["procs"],
         "kind": "port",
-        "sample": "%d independent worker processes (as mpirun -n %d), each %d rows x %d px of the "
-                  "synthetic block, %d CN raster(s), oracle_process_block_subset (src/cn.c:218-290 "
+        "sample": "%d independent worker processes (as mpirun -n %d, src/main.c:171), each %d rows x %d px of "
+                  "the synthetic block, %d CN raster(s), oracle_process_block_subset (src/cn.c:218-290 "
                   "loop structure, per-raster malloc/memcpy/memset, I/O excluded), gcc -O3 no -march; "
-                  "slowest worker %.1f s" % (r["multi"]["procs"], r["multi"]["procs"], rows, size, n_out,
-                                             r["multi"]["worker_seconds_max"]),
-        "single_core_value": round(r["single"]["gpx_per_s"], 4),
-        "host_cores_available": r["cores_available"],
+                  "slowest worker %.1f s" % (head["procs"], head["procs"], head["rows_per_proc"], size, n_out,
+                                             head["worker_seconds_max"]),
+        "runs": r["runs"],                              # P = 1, the 16-core share, all physical cores
+        "best_cpu": r.get("best_cpu"),                  # fused single pass, -O3 -march=native, all physical cores
+        "single_core_value": round(r["runs"][0]["gpx_per_s"], 4),
+        "host_cores_available": r["cores_available"], "host_physical_cores": r["physical_cores"],
+        "cpu_quota_cores": r.get("cpu_quota_cores"),
         "host_cpu": _host_cpu(),
     }
 
@@ -140,7 +151,78 @@ def traffic_from_profiles(workload: str):
         return None
 
 
-def main():
+def _numa_node_of(pci_bus_id: str):
+    try:
+        with open("/sys/bus/pci/devices/%s/numa_node" % pci_bus_id.lower()) as f:
+            return int(f.read().strip())
+    except (OSError, ValueError):
+        return None
+
+
+def _bind_to_numa_node(node):
+    """Run this rank on the cores next to its GPU (what bin/gcn10 does for its workers, pipeline.c)."""
+    if node is None or node < 0:
+        return None
+    try:
+        cpus = set()
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+            for part in f.read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            return len(cpus)
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def _stats(ms):
+    return {"avg_ms": round(float(np.mean(ms)), 4), "median_ms": round(float(np.median(ms)), 4),
+            "min_ms": round(float(np.min(ms)), 4)}
+
+
+def _load_engine_class():
+    """gcn10_amd.gpu.Engine -- or, for the launcher / aggregation tests only, the class named by
+    GCN10_BENCH_ENGINE (module:Class under tests/); the bench line then says so in `data`."""
+    spec = os.environ.get("GCN10_BENCH_ENGINE")
+    if not spec:
+        from gcn10_amd import gpu
+        return gpu.Engine, gpu.device_count, False
+    mod, _, cls = spec.partition(":")
+    klass = getattr(importlib.import_module(mod), cls)
+    return klass, klass.device_count, True
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N rank processes -- before this process
+    imports the GPU library or touches a device -- and pass rank 0's JSON line on."""
+    rdv = tempfile.mkdtemp(prefix="gcn10_rdv_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    procs = []
+    try:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                       GCN10_RDV_DIR=rdv, MASTER_ADDR="127.0.0.1")
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+        out0, _ = procs[0].communicate()
+        rcs = [p.wait() for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(rdv, ignore_errors=True)
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        raise SystemExit("bench.py: rank(s) failed: %s" % ", ".join("rank %d rc %d" % b for b in bad))
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -150,15 +232,19 @@ def main():
     ap.add_argument("--pattern", default="iid", choices=["iid", "patches"])
     ap.add_argument("--strip-rows", type=int, default=0, help="0 = whole block in one launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the short extra config4 measurement")
-    args = ap.parse_args()
+    ap.add_argument("--no-also", action="store_true", help="skip the extra config4 and copy measurements")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="rehearsal: let ranks share GPUs (rank r uses device r mod visible devices)")
+    args = ap.parse_args(argv)
 
     from gcn10_amd import shard
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args, argv)
+        return
     rank, local_rank, world = shard.world_from_env()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (one rank per GPU)" % args.gpus)
-        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d (run `python bench.py --gpus N` by itself, or under "
+                         "torch.distributed.run with --nproc-per-node N)" % (world, args.gpus))
 
     cond_mask, table_mask, preresampled = WORKLOADS[args.workload]
     n_out = bin(cond_mask).count("1") * bin(table_mask).count("1")
@@ -169,15 +255,23 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload, size)
 
-    from gcn10_amd import gpu, host
-    grp = shard.Group()                     # nccl (= RCCL) when WORLD_SIZE > 1, nothing otherwise
-    n_dev = gpu.device_count()
+    from gcn10_amd import host
+    Engine, device_count, fake_engine = _load_engine_class()
+    from gcn10_amd import gpu       # strip_algorithmic_bytes: a host-side formula of the C ABI
+    grp = shard.Group()             # files in a per-job directory; nothing at world size 1
+    n_dev = device_count()
     if n_dev < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    if local_rank >= n_dev and os.environ.get("GCN10_DIST_BACKEND") != "gloo":
-        raise SystemExit("rank %d has no GPU (only %d visible)" % (local_rank, n_dev))
-    eng = gpu.Engine(local_rank % n_dev)      # modulo only matters for the gloo rehearsal on one GPU
+    oversub = args.oversubscribe or os.environ.get("GCN10_BENCH_OVERSUBSCRIBE") == "1"
+    if local_rank >= n_dev and not oversub:
+        raise SystemExit("rank %d has no GPU (only %d visible); --oversubscribe shares GPUs for a rehearsal"
+                         % (local_rank, n_dev))
+    device = local_rank % n_dev
+    eng = Engine(device)
     info = eng.device_info()
+    bus = eng.pci_bus_id() if hasattr(eng, "pci_bus_id") else ""
+    numa = _numa_node_of(bus) if bus else None
+    bound = _bind_to_numa_node(numa) if world > 1 else None
     tables = host.load_all_lookup_tables(os.path.join(ROOT, "tests", "golden", "lookups"))
     eng.set_tables(tables)
 
@@ -187,6 +281,7 @@ def main():
     npix = size * size
     d_esa, d_coarse, d_ci, d_cj = eng.upload(esa), eng.upload(coarse), eng.upload(ci), eng.upload(cj)
     del esa
+    want_also = world == 1 and not args.no_also and args.workload == "config2" and not preresampled
     outs = [None] * 18
     out_bufs = []
     for r in range(18):
@@ -194,6 +289,8 @@ def main():
             b = eng.alloc(npix)
             out_bufs.append(b)
             outs[r] = b.ptr
+    # the extra config4 measurement writes 18 rasters: allocate them now, long before they are timed
+    extra = [eng.alloc(npix) for _ in range(17)] if want_also else []
     d_fine = None
     if preresampled:
         d_fine = eng.alloc(npix)
@@ -201,7 +298,7 @@ def main():
         eng.sync()
 
     strip = args.strip_rows or size
-    ev = [(eng.event_create(), eng.event_create()) for _ in range(args.steps)]
+    ev = [(eng.event_create(), eng.event_create()) for _ in range(max(args.steps, 20))]
 
     def step(i_timed=None):
         if preresampled:
@@ -225,27 +322,19 @@ def main():
         if i_timed is not None and not whole:
             eng.event_record(ev[i_timed][1])
 
-    def full_sync():
-        eng.device_sync()
-        if "torch" in sys.modules:
-            import torch
-            if torch.cuda.is_available():
-                torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
-    full_sync()
+    eng.device_sync()
     grp.barrier()
-    full_sync()
-    t0 = time.perf_counter()
+    eng.device_sync()
+    t_start = time.monotonic()
     for i in range(args.steps):
         step(i)
-    full_sync()
+    eng.device_sync()
+    t_end = time.monotonic()
     grp.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = grp.max(elapsed)
 
-    kernel_ms = [eng.elapsed_ms(a, b) for a, b in ev]
+    kernel_ms = [eng.elapsed_ms(a, b) for a, b in ev[:args.steps]]
     kname = "calculate_cn_kernel<true>" if preresampled else eng.last_kernel_name()
     launches = 1 if preresampled else (size + strip - 1) // strip
     avg_launch_s = float(np.mean(kernel_ms)) / 1e3 / launches
@@ -255,40 +344,88 @@ def main():
         alg_bytes = gpu.strip_algorithmic_bytes(size, size, hs, hs, cond_mask, table_mask) / launches
     achieved = alg_bytes / avg_launch_s / 1e9
 
+    def timed_launches(fn, n=20, warm=3):
+        """`fn()` launches one kernel; its dispatch carries the events (gcn10_gpu_time_next_strip)."""
+        for _ in range(warm):
+            fn()
+        eng.sync()
+        for i in range(n):
+            eng.time_next_strip(ev[i][0], ev[i][1])
+            fn()
+        eng.sync()
+        return [eng.elapsed_ms(a, b) for a, b in ev[:n]]
+
+    # what this GPU streams when a kernel only moves the bytes (1 B read : 1 B written), same run
+    copy = None
+    if not args.no_also and not preresampled and hasattr(eng, "stream_copy"):
+        nb = npix - npix % 16
+        ms = timed_launches(lambda: eng.stream_copy(d_esa.ptr, out_bufs[0].ptr, nb))
+        gbs = 2 * nb / float(np.mean(ms)) / 1e6
+        copy = dict(_stats(ms), kernel="stream_copy_kernel", bytes_per_launch=2 * nb,
+                    achieved_GBps=round(gbs, 1), frac_of_peak=round(gbs / HBM_PEAK_GBS, 4))
+
     also = None
-    if world == 1 and not args.no_also and args.workload == "config2" and not preresampled:
-        # the product's per-block pass (18 rasters fused), measured outside the timed region
+    if want_also:
+        # the product's per-block pass (18 rasters fused), outside the timed region, two ways:
+        # B = buffers allocated at start-up, 3 warm-ups, 20 launches, events carried by each dispatch
+        #     (the way `roofline` is measured);
+        # A = the round-1 form of this leg: 17 fresh allocations right before, one warm-up, 5 launches
+        #     between two separately recorded events.
         try:
+            b18 = gpu.strip_algorithmic_bytes(size, size, hs, hs, 3, 0x1FF)
+            all_outs = [out_bufs[0].ptr] + [b.ptr for b in extra]
+            eng.prepare_tile(d_coarse.ptr, hs, hs, d_ci.ptr, size)
+            ms_b = timed_launches(lambda: eng.cn_strip(d_esa.ptr, size, size, d_cj.ptr, 3, 0x1FF, all_outs))
+            k18 = eng.last_kernel_name()
+            for b in extra:
+                b.close()
             extra = [eng.alloc(npix) for _ in range(17)]
             all_outs = [out_bufs[0].ptr] + [b.ptr for b in extra]
             e0, e1 = eng.event_create(), eng.event_create()
-            n_rep = 5
-            eng.prepare_tile(d_coarse.ptr, hs, hs, d_ci.ptr, size)
             eng.cn_strip(d_esa.ptr, size, size, d_cj.ptr, 3, 0x1FF, all_outs)
             eng.sync()
             eng.event_record(e0)
-            for _ in range(n_rep):
+            for _ in range(5):
                 eng.cn_strip(d_esa.ptr, size, size, d_cj.ptr, 3, 0x1FF, all_outs)
             eng.event_record(e1)
             eng.sync()
-            ms = eng.elapsed_ms(e0, e1) / n_rep
-            b18 = gpu.strip_algorithmic_bytes(size, size, hs, hs, 3, 0x1FF)
-            also = {"workload": "config4 (18 rasters fused, kernel only)", "kernel": eng.last_kernel_name(),
-                    "ms_per_launch": round(ms, 4), "cn_gpx_per_s": round(npix * 18 / ms / 1e6, 2),
-                    "achieved_GBps": round(b18 / ms / 1e6, 1), "frac_of_peak": round(b18 / ms / 1e6 / HBM_PEAK_GBS, 4)}
+            ms_a = eng.elapsed_ms(e0, e1) / 5
+            gbs = b18 / float(np.mean(ms_b)) / 1e6
+            also = {"workload": "config4 (18 rasters fused, kernel only)", "kernel": k18,
+                    "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
+                    "traffic": traffic_from_profiles("config4") if (size == 36000 and args.pattern == "iid") else None,
+                    "algorithmic_bytes_per_launch": int(b18),
+                    "avg_launch_ms": _stats(ms_b)["avg_ms"], "median_launch_ms": _stats(ms_b)["median_ms"],
+                    "min_launch_ms": _stats(ms_b)["min_ms"],
+                    "cn_gpx_per_s": round(npix * 18 / float(np.mean(ms_b)) / 1e6, 2),
+                    "round1_style_ms_per_launch": round(ms_a, 4),
+                    "round1_style_note": "17 fresh 1.3 GB allocations right before, 1 warm-up, 5 launches "
+                                         "between two separately recorded events"}
+        except Exception as exc:       # never lose the bench line over the extra leg
+            also = {"error": str(exc)}
+        finally:
             for b in extra:
                 b.close()
-        except gpu.Gcn10GpuError as exc:
-            also = {"error": str(exc)}
 
+    mine = {"rank": rank, "device": device, "pci_bus_id": bus, "numa_node": numa, "cpus_bound": bound,
+            "t_start": t_start, "t_end": t_end, "elapsed_s": round(t_end - t_start, 6),
+            "kernel_avg_ms": round(avg_launch_s * 1e3, 4), "kernel": kname,
+            "copy_GBps": copy["achieved_GBps"] if copy else None}
+    ranks = grp.all_gather(mine)
     if rank == 0:
+        t0 = min(r["t_start"] for r in ranks)
+        elapsed = max(r["t_end"] for r in ranks) - t0        # whole job: first start to last end
+        for r in ranks:
+            r["start_offset_ms"] = round((r.pop("t_start") - t0) * 1e3, 3)
+            r["end_offset_ms"] = round((r.pop("t_end") - t0) * 1e3, 3)
         value = npix * n_out * world / elapsed * args.steps / 1e9
         line = {
             "metric": "CN Gpixels/sec", "value": round(value, 3), "unit": "Gpx/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
+            "dtype": "u8", "data": "synthetic" if not fake_engine else "FAKE ENGINE (launcher test, not a measurement)",
             "config": {"workload": "%s: one %dx%d uint8 landcover block per GPU, %s, %d CN raster(s) per step; "
                                    "soil %s" % (args.workload, size, size,
                                                 "lookup g_ii (ARC-II)" if n_out < 9 else "all 9 lookups",
@@ -296,7 +433,8 @@ def main():
                                                 "pre-resampled full-res tile" if preresampled
                                                 else "window %dx%d resampled in-kernel" % (hs, hs)),
                        "pattern": args.pattern, "strip_rows": strip, "blocks_per_step_per_gpu": 1,
-                       "device": info["name"], "cus": info["cus"]},
+                       "device": info["name"], "cus": info["cus"],
+                       "rank_sync": "none" if world == 1 else grp.backend},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          # the committed PMC passes were taken at the default shape only
@@ -305,12 +443,16 @@ def main():
                          "kernel": kname, "algorithmic_bytes_per_launch": int(alg_bytes),
                          "avg_launch_ms": round(avg_launch_s * 1e3, 4),
                          "median_launch_ms": round(float(np.median(kernel_ms)) / launches, 4),
-                         "min_launch_ms": round(float(np.min(kernel_ms)) / launches, 4)},
+                         "min_launch_ms": round(float(np.min(kernel_ms)) / launches, 4),
+                         "copy_ceiling": copy,
+                         "frac_of_copy": round(achieved / copy["achieved_GBps"], 4) if copy else None},
             "cpu_baseline": cpu,
+            "per_rank": ranks,
         }
         if also:
             line["also"] = also
         print(json.dumps(line))
+        sys.stdout.flush()
     grp.close()
     eng.close()
 

@@ -68,6 +68,7 @@ struct StripParams {
     uint32_t W;
     uint32_t rows;
     uint32_t npix;          // W*rows (< 2^31, as the reference's int npix, src/cn.c:208)
+    uint32_t nvec16;        // npix rounded down to a multiple of 16: the part done in 16-byte lane groups
     uint32_t hx_stride;
     uint32_t hx_rows;       // rows in hx; cj is clamped to it defensively
     uint32_t nchunks;
@@ -208,114 +209,93 @@ __device__ __forceinline__ uint32_t first_chunk(uint32_t nchunks, uint32_t &step
 //   the CN of all nine tables, so a pixel costs one ds_read_b128 per drainage
 //   condition whatever the number of rasters written; 4x4 byte transposes
 //   (v_perm_b32) turn "9 values of one pixel" into "4 pixels of one raster".
-// KIND = kLut1 (single table, BASELINE config 2): 2-3 B/px of HBM traffic, so
-//   the pixel rate is ~8x higher and the LDS work per pixel must be one byte
-//   read, not a 16-byte row.
-// ILP  = 4096-px sub-chunks a workgroup handles per loop trip; all their loads
-//   are issued before any is consumed (more HBM requests in flight per wave).
+// KIND = kLut1 (single table, BASELINE config 2): 2 B/px of HBM traffic, so the
+//   pixel rate is ~8x higher and the LDS work per pixel is one byte read.
+// ILP  = 1024-px wave chunks a wave handles per loop trip; all their loads are
+//   issued before any is consumed.
 // NT   = nontemporal landcover loads and raster stores.
+// PF   = software pipeline: the loads of trip t+1 are issued before trip t's
+//   gathers and stores, on two register sets used alternately (vmcnt counts
+//   loads and stores in one in-order queue on gfx950, so a wave that loads,
+//   stores, loads ... has nothing in flight while it gathers; with the next
+//   trip's loads issued first, its stores and those loads overlap).
+//
+// The loop body has no divergent region: a raster is processed as a flat byte
+// array in 16-byte lane groups, every lane of every wave issues the same loads,
+// and the three irregular cases are folded in without a branch that holds
+// memory operations --
+//   * lanes past the last full 16-byte group load from offset 0 and skip the
+//     store (exec mask on the store only); the npix % 16 tail pixels are done
+//     byte-wise after the loop;
+//   * lanes behind a row end inside the wave's 1024-px span use the next
+//     raster row's soil row (both coarse rows come through the scalar cache);
+//   * only when W % 16 != 0 can a lane's 16 pixels straddle a row end: the
+//     wave that holds such a lane (a scalar test, one wave in ~35) issues a
+//     second soil load for it that starts n bytes before the next soil row, and
+//     merges the two vectors with byte masks.
+// Requires W >= kMinVectorW so that a wave's span wraps at most once.
 // ------------------------------------------------------------------------
 enum { kLut16 = 0, kLut1 = 1 };
+constexpr uint32_t kWavePx = 64u * kPxPerLane;      // 1024 px per wave chunk
+constexpr uint32_t kMinVectorW = kWavePx + 16u;
 
-template <int KIND>
-__device__ __forceinline__ void slow_pixels(const StripParams &p, const uint8_t *lut,
-                                            uint32_t cond_mask, uint32_t tmask, uint32_t i0,
-                                            uint32_t y, uint32_t x0)
-{
-    // strip tail, or a lane whose 16 pixels straddle a row end
-    uint32_t yy = y, xx = x0;
-#pragma unroll 1
-    for (uint32_t q = 0; q < (uint32_t)kPxPerLane; q++) {
-        const uint32_t i = i0 + q;
-        if (i >= p.npix)
-            break;
-        const uint32_t lc = p.esa[i];
-        const uint32_t cd = p.hx[(size_t)soil_row(p, yy) * p.hx_stride + xx];
-#pragma unroll 1
-        for (int c = 0; c < 2; c++) {
-            if (!(cond_mask & (1u << c)))
-                continue;
-            const uint32_t s = (cd >> (4 * c)) & 0xfu;
-            if (KIND == kLut16) {
-                const uint8_t *row = lut + s * (uint32_t)kPlane16 + lc * 16u;
-                for (int k = 0; k < 9; k++)
-                    if (tmask & (1u << k))
-                        p.out[c * 9 + k][i] = row[k];
-            }
-            else {
-                p.out[c * 9 + p.single_k][i] = lut[s * (uint32_t)kPlane1 + lc];
-            }
-        }
-        if (++xx == p.W) {
-            xx = 0;
-            yy++;
-        }
-    }
-}
-
-// What one loop trip of a lane holds between issuing its loads and using them.
+// What a lane holds of one trip between issuing its loads and using them.
 template <int ILP>
 struct Trip {
-    uint32_t i0[ILP], y[ILP], x0[ILP];
-    bool live[ILP], fast[ILP];
     u32x4 e16[ILP], c16[ILP];
+    uint32_t i0[ILP];
 };
 
-// Addresses and all global loads of one trip (group of ILP sub-chunks), back to
-// back and branch free.
 template <int ILP, bool NT>
-__device__ __forceinline__ void issue_trip(const StripParams &p, uint32_t chunk, uint32_t lane_off,
+__device__ __forceinline__ void issue_trip(const StripParams &p, uint32_t trip, uint32_t lane_off,
                                            uint32_t wave_off, Trip<ILP> &tr)
 {
-    uint32_t row[ILP];
-    // ---- addresses.  The coarse rows of a wave's first pixel and of the next raster
-    // row come through the scalar cache (all scalar loads of the trip first, one wait),
-    // so the soil load below does not wait behind a vector load of cj ----
-    uint32_t wave_base[ILP], yb[ILP], xb[ILP], r0[ILP], r1[ILP];
+    // ---- wave-uniform part: row and column of the wave's first pixel, the coarse rows of that
+    // raster row and of the next one through the scalar cache (s_load, own counter) ----
+    uint32_t xb[ILP], r0[ILP], r1[ILP], wb[ILP];
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
-        wave_base[u] = __builtin_amdgcn_readfirstlane((chunk * ILP + u) * (uint32_t)kChunk + wave_off);
-        // past the strip's end the wave only needs valid addresses: row 0
-        const uint32_t wb = wave_base[u] < p.npix ? wave_base[u] : 0u;
-        yb[u] = wb / p.W;
-        xb[u] = wb - yb[u] * p.W;
-        r0[u] = (uint32_t)scalar_load_i32(p.cj, yb[u]);
-        r1[u] = (uint32_t)scalar_load_i32(p.cj, yb[u] + 1u < p.rows ? yb[u] + 1u : yb[u]);
+        wb[u] = __builtin_amdgcn_readfirstlane((trip * ILP + u) * (uint32_t)kChunk + wave_off);
+        const uint32_t wbc = wb[u] < p.npix ? wb[u] : 0u;   // a wave past the end only needs valid addresses
+        const uint32_t y = wbc / p.W;
+        xb[u] = wbc - y * p.W;
+        r0[u] = (uint32_t)scalar_load_i32(p.cj, y);
+        r1[u] = (uint32_t)scalar_load_i32(p.cj, y + 1u < p.rows ? y + 1u : y);
     }
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
-        tr.i0[u] = wave_base[u] + lane_off;
-        tr.live[u] = tr.i0[u] < p.npix;
-        uint32_t xx = xb[u] + lane_off;
-        const bool wrap = xx >= p.W;
-        uint32_t yy = wrap ? yb[u] + 1u : yb[u];
-        xx = wrap ? xx - p.W : xx;
-        row[u] = clamp_row(p, (int32_t)(wrap ? r1[u] : r0[u]));
-        if (xx >= p.W) {                    // rows narrower than a wave's span
-            const uint32_t q = xx / p.W;
-            yy += q;
-            xx -= q * p.W;
-            row[u] = tr.live[u] ? soil_row(p, yy) : 0u;
-        }
-        tr.y[u] = yy;
-        tr.x0[u] = xx;
-        tr.fast[u] = tr.live[u] && tr.i0[u] + kPxPerLane <= p.npix && xx + kPxPerLane <= p.W;
-    }
-    // ---- loads: a lane without a fast-path chunk reads the strip's first 16 bytes
-    // instead (the host guarantees npix >= 16 for this kernel), so no exec-masked
-    // region -- and no vmcnt(0) at its join -- separates them ----
-#pragma unroll
-    for (int u = 0; u < ILP; u++) {
-        const uint8_t *pe = p.esa + (tr.fast[u] ? tr.i0[u] : 0u);
+        tr.i0[u] = wb[u] + lane_off;
+        const uint8_t *pe = p.esa + (tr.i0[u] < p.nvec16 ? tr.i0[u] : 0u);
         tr.e16[u] = NT ? load16_aligned_nt(pe) : load16_aligned(pe);
     }
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
+        uint32_t xl = xb[u] + lane_off;
+        const bool wrap = xl >= p.W;
+        xl = wrap ? xl - p.W : xl;
+        const uint32_t row = clamp_row(p, (int32_t)(wrap ? r1[u] : r0[u]));
 #if defined(GCN10_DIAG) && (GCN10_DIAG == 2 || GCN10_DIAG == 3)
-        tr.c16[u] = u32x4{ row[u], tr.x0[u], 0u, 0u } & 0x11111111u;    // timing-only build: no soil load
+        tr.c16[u] = u32x4{ row, xl, 0u, 0u } & 0x11111111u;    // timing-only build: no soil load
 #else
-        const size_t off = tr.fast[u] ? (size_t)row[u] * p.hx_stride + tr.x0[u] : (size_t)0;
-        tr.c16[u] = load16_any(p.hx + off);
+        const uint8_t *pa = p.hx + (size_t)row * p.hx_stride + xl;
+        u32x4 a = load16_any(pa);
+        if (p.W & 15u) {
+            const uint32_t n = p.W - xl;            // pixels of this lane that are still in its row
+            const bool strad = !wrap && n < (uint32_t)kPxPerLane;
+            if (__builtin_amdgcn_ballot_w64(strad) != 0ull) {
+                // the other lanes of this wave re-read their own vector (an L1 hit)
+                const uint8_t *pb = strad ? p.hx + (size_t)clamp_row(p, (int32_t)r1[u]) * p.hx_stride - n : pa;
+                const u32x4 b = load16_any(pb);
+                const uint32_t nn = strad ? n : (uint32_t)kPxPerLane;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int32_t m = (int32_t)nn - 4 * j;      // bytes of dword j that come from a
+                    const uint32_t mask = m >= 4 ? 0xffffffffu : (m <= 0 ? 0u : (1u << (8 * m)) - 1u);
+                    a[j] = (a[j] & mask) | (b[j] & ~mask);
+                }
+            }
+        }
+        tr.c16[u] = a;
 #endif
     }
 }
@@ -327,12 +307,7 @@ __device__ __forceinline__ void finish_trip(const StripParams &p, const uint8_t 
 {
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
-        if (!tr.live[u])
-            continue;
-        if (!tr.fast[u]) {
-            slow_pixels<KIND>(p, lut, COND_MASK, tmask, tr.i0[u], tr.y[u], tr.x0[u]);
-            continue;
-        }
+        const bool live = tr.i0[u] < p.nvec16;
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             if (!(COND_MASK & (1 << c)))
@@ -357,11 +332,13 @@ __device__ __forceinline__ void finish_trip(const StripParams &p, const uint8_t 
                                  acc[6][j], acc[7][j]);
                     acc[8][j] = gather_byte0(r4[0][2], r4[1][2], r4[2][2], r4[3][2]);
                 }
+                if (live) {
 #pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    if (tmask & (1u << k)) {
-                        u32x4 v = {acc[k][0], acc[k][1], acc[k][2], acc[k][3]};
-                        store16<NT>(p.out[c * 9 + k] + tr.i0[u], v);
+                    for (int k = 0; k < 9; k++) {
+                        if (tmask & (1u << k)) {
+                            u32x4 v = {acc[k][0], acc[k][1], acc[k][2], acc[k][3]};
+                            store16<NT>(p.out[c * 9 + k] + tr.i0[u], v);
+                        }
                     }
                 }
             }
@@ -385,14 +362,13 @@ __device__ __forceinline__ void finish_trip(const StripParams &p, const uint8_t 
                     v[j] = w;
                 }
 #endif
-                store16<NT>(p.out[c * 9 + p.single_k] + tr.i0[u], v);
+                if (live)
+                    store16<NT>(p.out[c * 9 + p.single_k] + tr.i0[u], v);
             }
         }
     }
 }
 
-// PF: software prefetch -- the loads of trip i+1 are issued before trip i is
-// consumed, so a wave keeps requests in flight while it gathers and stores.
 template <int KIND, int COND_MASK, bool ALL_TABLES, int ILP, bool NT, bool PF>
 __global__ __launch_bounds__(kThreads) void cn_strip_kernel(const StripParams p)
 {
@@ -414,33 +390,87 @@ __global__ __launch_bounds__(kThreads) void cn_strip_kernel(const StripParams p)
     __syncthreads();
 
     const uint32_t lane_off = (threadIdx.x & 63u) * kPxPerLane;
-    const uint32_t wave_off = (threadIdx.x >> 6) * 64u * kPxPerLane;
+    const uint32_t wave_off = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * kWavePx;
     const uint32_t tmask = ALL_TABLES ? 0x1ffu : p.table_mask;
 
-    // p.nchunks counts trips (groups of ILP sub-chunks) here
+    // p.nchunks counts trips (groups of ILP chunks of 4096 px) here
     uint32_t step, end;
-    uint32_t chunk = first_chunk(p.nchunks, step, end, p.xcd_slabs != 0);
+    uint32_t trip = first_chunk(p.nchunks, step, end, p.xcd_slabs != 0);
     if (!PF) {
-        for (; chunk < end; chunk += step) {
+        for (; trip < end; trip += step) {
             Trip<ILP> tr;
-            issue_trip<ILP, NT>(p, chunk, lane_off, wave_off, tr);
+            issue_trip<ILP, NT>(p, trip, lane_off, wave_off, tr);
             finish_trip<KIND, COND_MASK, ILP, NT>(p, lut, tmask, tr);
         }
     }
-    else if (chunk < end) {
-        Trip<ILP> cur;
-        issue_trip<ILP, NT>(p, chunk, lane_off, wave_off, cur);
+    else if (trip < end) {
+        Trip<ILP> ta, tb;       // used alternately: a copy would wait for the loads it copies
+        issue_trip<ILP, NT>(p, trip, lane_off, wave_off, ta);
         for (;;) {
-            const uint32_t next = chunk + step;
-            if (next >= end)
+            trip += step;
+            if (trip >= end) {
+                finish_trip<KIND, COND_MASK, ILP, NT>(p, lut, tmask, ta);
                 break;
-            Trip<ILP> nxt;
-            issue_trip<ILP, NT>(p, next, lane_off, wave_off, nxt);
-            finish_trip<KIND, COND_MASK, ILP, NT>(p, lut, tmask, cur);
-            cur = nxt;
-            chunk = next;
+            }
+            issue_trip<ILP, NT>(p, trip, lane_off, wave_off, tb);
+            finish_trip<KIND, COND_MASK, ILP, NT>(p, lut, tmask, ta);
+            trip += step;
+            if (trip >= end) {
+                finish_trip<KIND, COND_MASK, ILP, NT>(p, lut, tmask, tb);
+                break;
+            }
+            issue_trip<ILP, NT>(p, trip, lane_off, wave_off, ta);
+            finish_trip<KIND, COND_MASK, ILP, NT>(p, lut, tmask, tb);
         }
-        finish_trip<KIND, COND_MASK, ILP, NT>(p, lut, tmask, cur);
+    }
+
+    // the last npix % 16 pixels, one per thread
+    if (blockIdx.x == 0 && threadIdx.x < p.npix - p.nvec16) {
+        const uint32_t i = p.nvec16 + threadIdx.x;
+        const uint32_t y = i / p.W;
+        const uint32_t x = i - y * p.W;
+        const uint32_t lc = p.esa[i];
+        const uint32_t cd = p.hx[(size_t)soil_row(p, y) * p.hx_stride + x];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            if (!(COND_MASK & (1 << c)))
+                continue;
+            const uint32_t s = (cd >> (4 * c)) & 0xfu;
+            if (KIND == kLut16) {
+                const uint8_t *row = lut + s * (uint32_t)kPlane16 + lc * 16u;
+                for (int k = 0; k < 9; k++)
+                    if (tmask & (1u << k))
+                        p.out[c * 9 + k][i] = row[k];
+            }
+            else {
+                p.out[c * 9 + p.single_k][i] = lut[s * (uint32_t)kPlane1 + lc];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
+// plain 1R:1W copy with the strip kernel's launch shape (XCD slabs, 16 B per
+// lane, two chunks per trip, nontemporal): what this device streams when a
+// kernel does nothing but move the bytes.  bench.py times it in the same run
+// as the strip kernel (gcn10_gpu_stream_copy).
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void stream_copy_kernel(const u32x4 *in, u32x4 *out, uint32_t nvec,
+                                                               uint32_t ntrips)
+{
+    uint32_t step, end;
+    for (uint32_t trip = first_chunk(ntrips, step, end, true); trip < end; trip += step) {
+        u32x4 v[2];
+        uint32_t idx[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            idx[u] = (trip * 2u + u) * (uint32_t)kThreads + threadIdx.x;
+            v[u] = __builtin_nontemporal_load(in + (idx[u] < nvec ? idx[u] : 0u));
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            if (idx[u] < nvec)
+                __builtin_nontemporal_store(v[u], out + idx[u]);
     }
 }
 
@@ -686,7 +716,7 @@ bool g_prefetch = true;     // set per launch by pick_strip_kernel
 template <int KIND, int ILP, bool NT>
 strip_kernel_t pick_by_mask(unsigned cond_mask, bool all)
 {
-    // prefetch variants exist for ILP 1 and 2 (ILP 4 already keeps 8 loads in flight)
+    // pipelined variants exist for ILP 1 and 2 (two register sets of ILP 4 cost occupancy)
     if (ILP <= 2 && g_prefetch)
         return pick_by_mask2<KIND, (ILP <= 2 ? ILP : 1), NT, true>(cond_mask, all);
     return pick_by_mask2<KIND, ILP, NT, false>(cond_mask, all);
@@ -833,8 +863,8 @@ void gcn10_gpu_destroy(gcn10_gpu_ctx *ctx)
         (void)hipFree(ctx->d_lut16);
     if (ctx->d_lut1)
         (void)hipFree(ctx->d_lut1);
-    if (ctx->d_hx)
-        (void)hipFree(ctx->d_hx);
+    if (ctx->d_hx_alloc)
+        (void)hipFree(ctx->d_hx_alloc);
     if (ctx->deflate_ws)
         (void)hipFree(ctx->deflate_ws);
     if (ctx->inflate_ws)
@@ -1238,13 +1268,16 @@ int gcn10_gpu_prepare_tile(gcn10_gpu_ctx *ctx, const uint8_t *coarse, int hsx, i
     const size_t need = (size_t)stride * (size_t)hsy;
     if (need > ctx->hx_capacity) {
         // growing the workspace is the one allocation on this path; it happens
-        // once per run for equally sized blocks (sync: the old buffer may be in use)
+        // once per run for equally sized blocks (sync: the old buffer may be in use).
+        // 16 bytes in front of row 0: the strip kernel's second soil load of a lane that
+        // straddles a row end starts up to 15 bytes before a soil row.
         HIP_TRY(hipDeviceSynchronize());
-        if (ctx->d_hx)
-            HIP_TRY(hipFree(ctx->d_hx));
-        ctx->d_hx = nullptr;
+        if (ctx->d_hx_alloc)
+            HIP_TRY(hipFree(ctx->d_hx_alloc));
+        ctx->d_hx_alloc = ctx->d_hx = nullptr;
         ctx->hx_capacity = 0;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_hx), need));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_hx_alloc), need + 16));
+        ctx->d_hx = ctx->d_hx_alloc + 16;
         ctx->hx_capacity = need;
     }
     ctx->hx_stride = stride;
@@ -1314,8 +1347,10 @@ int gcn10_gpu_cn_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, int rows,
     hipStream_t s = as_stream(ctx, stream);
 
     p.xcd_slabs = (uint32_t)ctx->xcd_slabs;
-    if (p.npix < 16u)
-        all_aligned = false;        // the vector kernels read 16 bytes unconditionally
+    p.nvec16 = p.npix & ~15u;
+    // the vector kernel wants a wave's 1024-px span to cross at most one row end
+    if (p.npix < 16u || p.W < kMinVectorW)
+        all_aligned = false;
     if (!all_aligned) {
         p.lut = ctx->d_lut16;
         const uint32_t g = stream_grid(ctx, ((uint64_t)p.npix + kThreads - 1) / kThreads);
@@ -1325,8 +1360,7 @@ int gcn10_gpu_cn_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, int rows,
     else {
         const bool single = popcount(table_mask) == 1;
         const bool all = table_mask == 0x1ffu;
-        // 0 = by the number of store streams: two sub-chunks per trip up to nine rasters, one beyond
-        // (measured: 9 rasters 2.11 vs 2.30 ms, 18 rasters 3.96 vs 4.05 ms)
+        // 0 = by the number of store streams: two chunks per trip up to nine rasters, one beyond
         const int n_streams = popcount(cond_mask) * popcount(table_mask);
         const int ilp = single ? ctx->ilp1 : (ctx->ilp16 > 0 ? ctx->ilp16 : (n_streams > 9 ? 1 : 2));
         const bool nt = ctx->nontemporal != 0;
@@ -1339,8 +1373,7 @@ int gcn10_gpu_cn_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, int rows,
         }
         p.nchunks = (p.nchunks + (uint32_t)ilp - 1) / (uint32_t)ilp;    // groups of ILP sub-chunks
         const uint32_t grid = stream_grid(ctx, p.nchunks);
-        // prefetch: measured +1.5 % on the 18-raster kernel, -1 % on the single-raster one
-        const bool pf = (ctx->prefetch < 0 ? !single : ctx->prefetch != 0) && ilp <= 2;
+        const bool pf = ctx->prefetch != 0 && ilp <= 2;
         strip_kernel_t fn = pick_strip_kernel(single, cond_mask, all, ilp, nt, pf);
         if (!fn)
             return fail(GCN10_E_INVAL, "gcn10_gpu_cn_strip: no kernel for ilp=%d", ilp);
@@ -1381,7 +1414,18 @@ int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value)
 {
     if (!ctx || !name)
         return fail(GCN10_E_INVAL, "gcn10_gpu_set_option: null argument");
-    if (!strcmp(name, "grid_blocks_per_cu") && value >= 1 && value <= 64)
+    if (!strcmp(name, "defaults")) {
+        const gcn10_gpu_ctx fresh;
+        ctx->grid_blocks_per_cu = fresh.grid_blocks_per_cu;
+        ctx->ilp16 = fresh.ilp16;
+        ctx->ilp1 = fresh.ilp1;
+        ctx->nontemporal = fresh.nontemporal;
+        ctx->xcd_slabs = fresh.xcd_slabs;
+        ctx->prefetch = fresh.prefetch;
+        ctx->deflate_wave_codes = fresh.deflate_wave_codes;
+        ctx->fused_diag = fresh.fused_diag;
+    }
+    else if (!strcmp(name, "grid_blocks_per_cu") && value >= 1 && value <= 64)
         ctx->grid_blocks_per_cu = value;
     else if (!strcmp(name, "ilp16") && (value == 0 || value == 1 || value == 2))
         ctx->ilp16 = value;
@@ -1408,6 +1452,34 @@ int gcn10_gpu_time_next_strip(gcn10_gpu_ctx *ctx, gcn10_event_t start, gcn10_eve
         return fail(GCN10_E_INVAL, "gcn10_gpu_time_next_strip: null argument");
     ctx->time_start = reinterpret_cast<hipEvent_t>(start);
     ctx->time_stop = reinterpret_cast<hipEvent_t>(stop);
+    return GCN10_OK;
+}
+
+int gcn10_gpu_stream_copy(gcn10_gpu_ctx *ctx, const void *src, void *dst, size_t bytes, gcn10_stream_t stream)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (bytes == 0)
+        return GCN10_OK;
+    if (!src || !dst || (bytes & 15u) || !aligned16(src) || !aligned16(dst) || bytes / 16 > 0x7fffffffull)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_stream_copy: needs 16-byte aligned pointers and size (< 32 GiB)");
+    const u32x4 *in = static_cast<const u32x4 *>(src);
+    u32x4 *out = static_cast<u32x4 *>(dst);
+    uint32_t nvec = (uint32_t)(bytes / 16);
+    uint32_t ntrips = (nvec + 2u * kThreads - 1u) / (2u * kThreads);
+    const uint32_t grid = stream_grid(ctx, ntrips);
+    hipStream_t s = as_stream(ctx, stream);
+    if (ctx->time_start && ctx->time_stop) {
+        void *args[] = { &in, &out, &nvec, &ntrips };
+        HIP_TRY(hipExtLaunchKernel(reinterpret_cast<const void *>(stream_copy_kernel), dim3(grid), dim3(kThreads),
+                                   args, 0, s, ctx->time_start, ctx->time_stop, 0));
+        ctx->time_start = ctx->time_stop = nullptr;
+    }
+    else {
+        hipLaunchKernelGGL(stream_copy_kernel, dim3(grid), dim3(kThreads), 0, s, in, out, nvec, ntrips);
+    }
+    HIP_TRY(hipGetLastError());
     return GCN10_OK;
 }
 

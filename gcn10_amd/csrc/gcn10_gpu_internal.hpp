@@ -39,7 +39,8 @@ struct gcn10_gpu_ctx {
     uint8_t *d_lut16 = nullptr;     // kLut16Bytes
     uint8_t *d_lut1 = nullptr;      // 9 * kLut1Bytes
     int n_tables = 0;
-    uint8_t *d_hx = nullptr;
+    uint8_t *d_hx = nullptr;        // row 0 of the soil-code workspace (= d_hx_alloc + 16)
+    uint8_t *d_hx_alloc = nullptr;
     size_t hx_capacity = 0;
     uint32_t hx_stride = 0;
     uint32_t hx_W = 0;
@@ -52,8 +53,8 @@ struct gcn10_gpu_ctx {
     int ilp1 = 2;           // same, single-table kernel (1, 2, 4)
     int nontemporal = 1;
     int xcd_slabs = 1;
-    int prefetch = -1;      // loads of the next trip issued before the current one is consumed:
-                            // -1 = per kernel default (on for all-tables, off for single-table)
+    int prefetch = 1;       // software pipeline: loads of the next trip issued before the current one is
+                            // consumed (two register sets; -1 = default = on)
     hipEvent_t time_start = nullptr, time_stop = nullptr;  // one-shot: bracket the next strip kernel
     uint8_t *d_class_of = nullptr;  // [36][256] pixel class of (soil code, landcover), then [18][256] values
     int n_classes = 0;              // 0: not available (set_tables not called, or > 256 classes)

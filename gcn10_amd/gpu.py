@@ -41,7 +41,7 @@ ABI_SYMBOLS = (
     "gcn10_gpu_deflate_arena_bound", "gcn10_gpu_deflate_strip", "gcn10_gpu_time_next_strip",
     "gcn10_gpu_pci_bus_id", "gcn10_gpu_deflate_fused_strip",
     "gcn10_gpu_deflate_fused_available",
-    "gcn10_gpu_inflate_tiles",
+    "gcn10_gpu_inflate_tiles", "gcn10_gpu_stream_copy",
 )
 
 
@@ -100,6 +100,7 @@ def lib():
             "gcn10_gpu_last_kernel_name": (C.c_char_p, [vp]),
             "gcn10_gpu_set_option": (i, [vp, C.c_char_p, i]),
             "gcn10_gpu_time_next_strip": (i, [vp, vp, vp]),
+            "gcn10_gpu_stream_copy": (i, [vp, vp, vp, sz, vp]),
             "gcn10_gpu_pci_bus_id": (i, [i, C.c_char_p, sz]),
             "gcn10_gpu_deflate_fused_strip": (i, [vp, vp, i, i, vp, u, u, vp, sz, vp, vp, vp]),
             "gcn10_gpu_deflate_fused_available": (i, [vp]),
@@ -262,6 +263,10 @@ class Engine:
 
     def time_next_strip(self, e0, e1):
         self._chk(lib().gcn10_gpu_time_next_strip(self._ctx, e0, e1), "gcn10_gpu_time_next_strip")
+
+    def stream_copy(self, src, dst, nbytes: int, stream=None):
+        """Plain 1R:1W copy with the strip kernel's launch shape (the same-run streaming ceiling)."""
+        self._chk(lib().gcn10_gpu_stream_copy(self._ctx, src, dst, int(nbytes), stream), "gcn10_gpu_stream_copy")
 
     def last_kernel_name(self) -> str:
         return lib().gcn10_gpu_last_kernel_name(self._ctx).decode()

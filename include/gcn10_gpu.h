@@ -234,15 +234,24 @@ int gcn10_gpu_inflate_tiles(gcn10_gpu_ctx *ctx, const uint8_t *comp_dev,
 
 /* Launch-shape knobs of the strip kernels, for tuning runs; results never
  * depend on them.  Names: "grid_blocks_per_cu" (1..64), "ilp16" (0 = by raster count | 1 | 2),
- * "ilp1" (1|2|4), "nontemporal" (0|1), "xcd_slabs" (0|1), "prefetch" (-1 = per-kernel default | 0 | 1), "deflate_wave_codes" (0|1: code
+ * "ilp1" (1|2|4), "nontemporal" (0|1), "xcd_slabs" (0|1), "prefetch" (software pipeline of the strip kernels: -1 = default = on | 0 | 1), "deflate_wave_codes" (0|1: code
  * construction of the tile encoder by one thread or one wave per tile), "fused_diag" (timing
- * experiments on the fused encoder; nonzero values produce invalid streams). */
+ * experiments on the fused encoder; nonzero values produce invalid streams), "defaults" (value
+ * ignored: every knob back to its built-in default). */
 int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value);
 
 /* Measurement: the next gcn10_gpu_cn_strip launch records `start` / `stop` as part of
  * the kernel dispatch itself (hipExtLaunchKernel), so gcn10_gpu_event_elapsed_ms gives
  * the kernel's own duration -- the figure rocprofv3 --kernel-trace reports. One shot. */
 int gcn10_gpu_time_next_strip(gcn10_gpu_ctx *ctx, gcn10_event_t start, gcn10_event_t stop);
+
+/* Measurement: a plain copy of `bytes` (a multiple of 16, both pointers 16-byte aligned)
+ * from `src` to `dst`, with the strip kernel's launch shape and nothing but the two
+ * streams: what this device sustains for 1 byte read : 1 byte written.  bench.py times
+ * it next to the strip kernel, in the same run.  Honours gcn10_gpu_time_next_strip.
+ * Kernel name in profiles: stream_copy_kernel.  No counterpart in the reference. */
+int gcn10_gpu_stream_copy(gcn10_gpu_ctx *ctx, const void *src, void *dst, size_t bytes,
+                          gcn10_stream_t stream);
 
 /* Name of the variant of the strip kernel the last cn_strip call launched
  * (for profiles and bench records). */

@@ -88,12 +88,14 @@ def test_calculate_cn_equals_oracle(engine, n, offset):
 
 
 def test_all_65536_pairs_both_kernels(eng9, tables):
-    """esa[y][x] = y, soil = x: every (class, soil code) pair through all 18 rasters."""
-    esa = np.repeat(np.arange(256, dtype=np.uint8)[:, None], 256, axis=1)
+    """esa[y][x] = y, soil = x // 8: every (class, soil code) pair through all 18 rasters
+    (2048 px wide: the 16-byte-per-lane kernels need rows of at least 1040 px)."""
+    esa = np.repeat(np.arange(256, dtype=np.uint8)[:, None], 2048, axis=1)
     coarse = np.arange(256, dtype=np.uint8)[None, :]
     gt = [0.0, 1.0, 0.0, 0.0, 0.0, -1.0]
-    sgt = [0.5, 1.0, 0.0, 0.0, 0.0, -1.0]
+    sgt = [4.0, 8.0, 0.0, 0.0, 0.0, -1.0]            # ci[x] = round((x + 0.5 - 4) / 8) = x // 8
     want = oc.process_block_mem(esa, gt, coarse, sgt, tables)
+    assert all(len(np.unique(want[r])) > 1 for r in range(18))
     got = eng9.process_block_mem(esa, gt, coarse, sgt)
     assert eng9.last_kernel_name().startswith("cn_strip_kernel<0,")
     assert np.array_equal(got, want)
@@ -108,7 +110,11 @@ def test_all_65536_pairs_both_kernels(eng9, tables):
 
 SHAPES = [(1, 1), (1, 15), (1, 16), (1, 17), (17, 1), (5, 3), (3, 5000), (64, 64), (257, 131),
           (300, 300), (64, 1040), (33, 4099), (130, 1024), (9, 36001 // 9),
-          (70, 36001)]        # the real block width: rows not 16-byte aligned
+          (70, 36001),        # the real block width: rows not 16-byte aligned
+          # widths around the vector kernel's lower bound (1040) and odd widths above it: lanes
+          # whose 16 pixels straddle a row end, row ends inside a wave's 1024-px span, npix % 16 != 0
+          (3, 1039), (5, 1041), (41, 1055), (7, 2047), (21, 2049), (2, 36001), (1, 1040), (1, 70001),
+          (19, 8193)]
 
 
 @pytest.mark.parametrize("shape", SHAPES)
@@ -138,6 +144,51 @@ def test_subsets(eng9, tables, cond_mask, table_mask):
                                 table_mask=table_mask)
     got = eng9.process_block_mem(esa, gt, coarse, sgt, cond_mask=cond_mask, table_mask=table_mask)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("cond_mask", [1, 2, 3])
+@pytest.mark.parametrize("table_mask", [0x1FF, 0x001, 0x080, 0x0A5])
+@pytest.mark.parametrize("W", [1043, 2064])
+def test_subsets_vector_kernels(eng9, tables, cond_mask, table_mask, W):
+    """The same subsets at widths the 16-byte-per-lane kernels take (1043: rows not 16-byte aligned)."""
+    esa, gt, coarse, sgt = make_block(cond_mask * 1000 + table_mask + W, 37, W, 4, W // 25 + 2, nasty=True)
+    want = oc.process_block_mem(esa, gt, coarse, sgt, tables, cond_mask=cond_mask, table_mask=table_mask)
+    got = eng9.process_block_mem(esa, gt, coarse, sgt, cond_mask=cond_mask, table_mask=table_mask)
+    assert eng9.last_kernel_name().startswith("cn_strip_kernel<")
+    assert np.array_equal(got, want)
+
+
+def test_launch_shape_knobs_never_change_results(eng9, tables):
+    """gcn10_gpu_set_option: chunks per trip, software pipeline, store policy, XCD slabs, grid size."""
+    W, H = 3001, 53
+    esa, gt, coarse, sgt = make_block(4242, H, W, 5, 123, nasty=True)
+    want18 = oc.process_block_mem(esa, gt, coarse, sgt, tables)
+    want1 = oc.process_block_mem(esa, gt, coarse, sgt, tables, cond_mask=2, table_mask=1 << 4)
+    try:
+        for ilp1, ilp16, pf, nt, xcd, bpc in [(1, 1, 0, 1, 1, 8), (1, 1, 1, 0, 0, 1), (2, 2, 1, 1, 1, 16),
+                                              (2, 2, 0, 0, 1, 3), (4, 0, 1, 1, 0, 8), (4, 0, 0, 1, 1, 2)]:
+            for name, v in (("ilp1", ilp1), ("ilp16", ilp16), ("prefetch", pf), ("nontemporal", nt),
+                            ("xcd_slabs", xcd), ("grid_blocks_per_cu", bpc)):
+                eng9.set_option(name, v)
+            assert np.array_equal(eng9.process_block_mem(esa, gt, coarse, sgt), want18)
+            got1 = eng9.process_block_mem(esa, gt, coarse, sgt, cond_mask=2, table_mask=1 << 4)
+            assert np.array_equal(got1, want1)
+    finally:
+        eng9.set_option("defaults", 0)
+
+
+def test_stream_copy_is_a_copy(engine):
+    n = 16 * 100003
+    src = np.random.default_rng(5).integers(0, 256, size=n, dtype=np.uint8)
+    a, b = engine.upload(src), engine.alloc(n + 32)
+    engine.memset(b.ptr, 0x33, n + 32)
+    engine.stream_copy(a.ptr, b.ptr, n)
+    engine.sync()
+    got = engine.download(b.ptr, (n + 32,))
+    assert np.array_equal(got[:n], src) and (got[n:] == 0x33).all()
+    with pytest.raises(gpu.Gcn10GpuError):
+        engine.stream_copy(a.ptr, b.ptr, 17)
+    a.close(); b.close()
 
 
 @pytest.mark.parametrize("n_tables", [1, 2, 5, 9])
