@@ -197,28 +197,37 @@ def _load_engine_class():
 
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: start N rank processes -- before this process
-    imports the GPU library or touches a device -- and pass rank 0's JSON line on."""
+    imports the GPU library or touches a device -- and pass rank 0's JSON line on.  A rank that fails
+    ends the job: the others are stopped instead of waiting for it at the barrier."""
     rdv = tempfile.mkdtemp(prefix="gcn10_rdv_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     procs = []
+    out0 = open(os.path.join(rdv, "rank0.stdout"), "w+")
     try:
         for r in range(args.gpus):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                        GCN10_RDV_DIR=rdv, MASTER_ADDR="127.0.0.1")
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-        out0, _ = procs[0].communicate()
-        rcs = [p.wait() for p in procs]
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        failed = []
+        while True:
+            rcs = [p.poll() for p in procs]
+            failed = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+            if failed or all(rc == 0 for rc in rcs):
+                break
+            time.sleep(0.05)
+        out0.seek(0)
+        sys.stdout.write(out0.read())
+        sys.stdout.flush()
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
+                p.wait()
+        out0.close()
         shutil.rmtree(rdv, ignore_errors=True)
-    sys.stdout.write(out0 or "")
-    sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        raise SystemExit("bench.py: rank(s) failed: %s" % ", ".join("rank %d rc %d" % b for b in bad))
+    if failed:
+        raise SystemExit("bench.py: rank(s) failed: %s" % ", ".join("rank %d rc %d" % b for b in failed))
 
 
 def main(argv=None):

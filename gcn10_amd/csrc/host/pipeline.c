@@ -525,6 +525,11 @@ static int process_block(struct worker *w, int block_id)
     if (r->gpu_inflate) {
         int irc = gcn10_inflate_block(w, xoff, yoff, W, H, block_id);
 
+        if (irc == -2) {
+            rc = -1;                /* device error: fatal like every other GPU error here (the worker's
+                                     * streams are synchronised at `out` before any buffer is reused) */
+            goto out;
+        }
         if (irc < 0) {
             goto out;               /* logged; the block is skipped as after a failed load_raster */
         }

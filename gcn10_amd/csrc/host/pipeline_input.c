@@ -128,8 +128,10 @@ int gcn10_inflate_block(struct worker *w, int xoff, int yoff, int W, int H, int 
             goto gpu_fail;
         w->h_comp_cap = w->d_comp_cap = cap;
     }
-    if (ensure_dev(w, (void **)&w->d_block, &w->block_cap, (size_t)W * (size_t)H) != 0)
+    if (ensure_dev(w, (void **)&w->d_block, &w->block_cap, (size_t)W * (size_t)H) != 0) {
+        rc = -2;        /* ensure_dev logged it: a device allocation failed */
         goto out;
+    }
     /* compressed bytes: a few dozen chunks per pool job */
     for (size_t i = 0; i < plan.n; i += 32) {
         struct comp_job *j = malloc(sizeof *j);
@@ -191,7 +193,10 @@ int gcn10_inflate_block(struct worker *w, int xoff, int yoff, int W, int H, int 
     goto out;
 
 gpu_fail:
+    /* a device error (allocation, copy, launch) is not a failed load_raster: the caller ends the
+     * run with it, like every other GPU error of process_block, instead of skipping the block */
     wlog(w, "ERROR", true, "gpu: %s", g->last_error());
+    rc = -2;
 out:
     /* the files may close: the compressed bytes are in pinned memory now */
     gcn10_read_plan_free(&plan);

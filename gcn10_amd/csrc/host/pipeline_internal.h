@@ -114,7 +114,8 @@ int gcn10_ensure_dev(struct worker *w, void **p, size_t *cap, size_t need);
 
 /* pipeline_input.c: landcover window of a block -> w->d_block through the GPU decoder.
  * 0 = issued on s_kernel (statuses arrive with ev_inflate), 1 = this window needs the host
- * reader, -1 = error (logged). */
+ * reader, -1 = the window cannot be read or decoded (logged; the block is skipped as after a failed
+ * load_raster, src/cn.c:188-192), -2 = device error (logged; fatal for the run). */
 int gcn10_inflate_block(struct worker *w, int xoff, int yoff, int W, int H, int block_id);
 
 #endif

@@ -193,6 +193,12 @@ class Engine:
             self._chk(cus, "gcn10_gpu_device_info")
         return {"name": name.value.decode(), "cus": cus, "hbm_bytes": hbm.value}
 
+    def pci_bus_id(self) -> str:
+        """PCI bus id of this engine's device, e.g. 0000:05:00.0."""
+        buf = C.create_string_buffer(32)
+        self._chk(lib().gcn10_gpu_pci_bus_id(self.device, buf, 32), "gcn10_gpu_pci_bus_id")
+        return buf.value.decode()
+
     def alloc(self, nbytes: int) -> DevBuf:
         return DevBuf(self, nbytes)
 

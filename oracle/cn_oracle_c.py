@@ -138,3 +138,46 @@ def process_block_mem(esa, gt, coarse, soil_gt, tables, cond_mask=3, table_mask=
     if rc != 0:
         raise MemoryError("oracle_process_block_subset")
     return out
+
+
+# ---- the fused "best CPU" pass (cn_fused_cpu.c, built -march=native for the host it runs on) ----
+_NATIVE_PATH = os.path.join(_HERE, "libcn_fused_native.so")
+_native = None
+
+
+def build_native(force: bool = True) -> str:
+    """(Re)build libcn_fused_native.so HERE: -march=native code built on another machine may not run."""
+    if force or not os.path.exists(_NATIVE_PATH):
+        subprocess.run(["make", "-C", _HERE, "-B", "libcn_fused_native.so"], check=True, capture_output=True)
+    return _NATIVE_PATH
+
+
+def fused_block(esa, gt, coarse, soil_gt, tables, cond_mask=3, table_mask=0x1FF, want_output=True, _out=None):
+    """One fused pass over a block: the same rasters as process_block_mem (index maps from
+    oracle_index_maps).  `_out`: a list of 18 uint8[H,W] arrays (None where a raster is not selected)
+    to write into instead of a fresh uint8[18,H,W]; with want_output=False nothing is returned."""
+    global _native
+    if _native is None:
+        build_native(force=not os.path.exists(_NATIVE_PATH))
+        N = C.CDLL(_NATIVE_PATH)
+        N.oracle_fused_block.argtypes = [_u8p, C.c_int, C.c_int, _u8p, C.c_int, _i32p, _i32p, _i32p,
+                                         C.c_uint, C.c_uint, C.POINTER(C.c_void_p)]
+        N.oracle_fused_block.restype = C.c_int
+        _native = N
+    esa = np.ascontiguousarray(esa, dtype=np.uint8)
+    coarse = np.ascontiguousarray(coarse, dtype=np.uint8)
+    tables = np.ascontiguousarray(tables, dtype=np.int32).reshape(9, 256, 5)
+    H, W = esa.shape
+    hsy, hsx = coarse.shape
+    ci, cj = index_maps(gt, soil_gt, W, H, hsx, hsy)
+    out = _out if _out is not None else np.zeros((18, H, W), dtype=np.uint8)
+    ptrs = (C.c_void_p * 18)()
+    for i in range(18):
+        if (cond_mask >> (i // 9)) & 1 and (table_mask >> (i % 9)) & 1:
+            assert out[i] is not None and out[i].shape == (H, W) and out[i].flags.c_contiguous
+            ptrs[i] = out[i].ctypes.data
+    rc = _native.oracle_fused_block(esa.reshape(-1), W, H, coarse.reshape(-1), hsx, ci, cj, tables.reshape(-1),
+                                    cond_mask, table_mask, ptrs)
+    if rc != 0:
+        raise MemoryError("oracle_fused_block")
+    return out if want_output else None

@@ -1,9 +1,14 @@
-"""The N > 1 path on CPUs: world_size-2 gloo runs of the rank plumbing bench.py uses,
+"""The N > 1 path on CPUs: world-size-2 runs of the rank plumbing bench.py uses (files by default,
+torch.distributed/gloo on request), bench.py's own launcher and aggregation with a stand-in engine,
 and the block-distribution rules.  (The GPU data path has no collective to test.)"""
+import json
 import os
+import socket
 import subprocess
 import sys
 import textwrap
+
+import pytest
 
 from gcn10_amd import shard
 from tests.conftest import ROOT
@@ -21,52 +26,142 @@ def test_round_robin_share_matches_reference_loop():
     assert got == sorted(ids)
 
 
-def test_world_size_one_needs_no_torch_distributed(monkeypatch):
+def test_world_size_one_needs_nothing(monkeypatch):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         monkeypatch.delenv(k, raising=False)
     g = shard.Group()
     assert (g.rank, g.world) == (0, 1)
     g.barrier()
-    assert g.max(3.5) == 3.5 and g.sum(2.0) == 2.0
+    assert g.max(3.5) == 3.5 and g.sum(2.0) == 2.0 and g.all_gather({"a": 1}) == [{"a": 1}]
     g.close()
+    assert "torch" not in sys.modules or True      # importing shard never imports torch (checked below)
 
 
-def test_gloo_world_size_two(tmp_path):
-    script = tmp_path / "w.py"
-    script.write_text(textwrap.dedent("""
-        import json, os, sys
-        sys.path.insert(0, %r)
-        from gcn10_amd import shard
-        g = shard.Group(backend="gloo")
-        g.barrier()
-        elapsed = 1.0 + g.rank            # rank 1 is the slow one
-        worst = g.max(elapsed)
-        total = g.sum(10.0 * (g.rank + 1))
-        mine = shard.blocks_for_rank(list(range(10, 21)), g.rank, g.world)
-        g.barrier()
-        with open(os.path.join(%r, "rank%%d.json" %% g.rank), "w") as f:     # one file per rank:
-            json.dump({"rank": g.rank, "world": g.world, "worst": worst,      # stdout of two ranks interleaves
-                       "total": total, "mine": mine}, f)
-        g.close()
-    """ % (ROOT, str(tmp_path))))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    import socket
+def test_shard_and_bench_do_not_import_torch():
+    code = "import sys; sys.path.insert(0, %r); import bench; from gcn10_amd import shard; " \
+           "shard.Group(); print('torch' in sys.modules)" % ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip() == "False"
+
+
+WORKER = """
+    import json, os, sys
+    sys.path.insert(0, %r)
+    from gcn10_amd import shard
+    g = shard.Group(%s)
+    g.barrier()
+    elapsed = 1.0 + g.rank            # rank 1 is the slow one
+    worst = g.max(elapsed)
+    total = g.sum(10.0 * (g.rank + 1))
+    everyone = g.all_gather({"rank": g.rank, "pid": os.getpid()})
+    mine = shard.blocks_for_rank(list(range(10, 21)), g.rank, g.world)
+    g.barrier()
+    with open(os.path.join(%r, "rank%%d.json" %% g.rank), "w") as f:     # one file per rank:
+        json.dump({"rank": g.rank, "world": g.world, "worst": worst,      # stdout of two ranks interleaves
+                   "total": total, "mine": mine, "backend": g.backend,
+                   "ranks_seen": [e["rank"] for e in everyone], "torch": "torch" in sys.modules}, f)
+    g.close()
+"""
+
+
+def _free_port():
     with socket.socket() as sk:           # a port nobody holds right now
         sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+        return sk.getsockname()[1]
+
+
+@pytest.mark.parametrize("backend", ["file", "gloo"])
+def test_world_size_two_under_torchrun(tmp_path, backend):
+    """The driver's launch line: torch.distributed.run starts the ranks; the group itself is files
+    (default, no torch in the ranks) or gloo when asked for."""
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent(WORKER % (ROOT, "" if backend == "file" else "backend='gloo'", str(tmp_path))))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("GCN10_RDV_DIR", None)
+    env.pop("GCN10_DIST_BACKEND", None)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    import json
     recs = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
     assert [r["rank"] for r in recs] == [0, 1] and all(r["world"] == 2 for r in recs)
     assert all(r["worst"] == 2.0 and r["total"] == 30.0 for r in recs)       # max / sum over ranks
+    assert all(r["ranks_seen"] == [0, 1] and r["backend"] == backend for r in recs)
     assert recs[0]["mine"] == [10, 12, 14, 16, 18, 20] and recs[1]["mine"] == [11, 13, 15, 17, 19]
+    if backend == "file":
+        assert not any(r["torch"] for r in recs)
 
 
-def test_bench_refuses_a_world_size_mismatch():
-    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"],
-                         capture_output=True, text=True, env=env, timeout=120)
-    assert out.returncode != 0 and "torch.distributed.run" in (out.stderr + out.stdout)
+def test_file_group_times_out_when_a_rank_is_missing(tmp_path):
+    g = shard.FileGroup(0, 2, directory=str(tmp_path / "rdv"), timeout_s=0.3)
+    with pytest.raises(TimeoutError):
+        g.barrier()
+
+
+FAKE = dict(GCN10_BENCH_ENGINE="tests.fake_engine:FakeEngine", GCN10_FAKE_DEVICES="2", GCN10_FAKE_LAUNCH_S="0.004")
+
+
+def _bench(args, extra_env=None, launcher=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GCN10_RDV_DIR")}
+    env.update(FAKE)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env.update(extra_env or {})
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + args
+    return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+
+
+def test_bench_starts_its_own_ranks_and_aggregates():
+    """`python bench.py --gpus 2` with no launcher: two rank processes, one JSON line, per-rank records,
+    whole-job time = first start to last end (the stand-in engine makes rank 1 the slower one)."""
+    out = _bench(["--gpus", "2", "--steps", "5", "--warmup", "1", "--size", "2048", "--no-cpu-baseline"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 5 and rec["scaling"] == "weak"
+    assert rec["data"].startswith("FAKE ENGINE") and rec["config"]["rank_sync"] == "file"
+    pr = rec["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and [r["device"] for r in pr] == [0, 1]
+    assert pr[0]["pci_bus_id"] != pr[1]["pci_bus_id"]
+    assert pr[1]["elapsed_s"] > pr[0]["elapsed_s"] * 1.2                      # device 1 sleeps 1.5x
+    span = max(r["end_offset_ms"] for r in pr)
+    assert abs(rec["ms_per_step"] * 5 - span) < 0.5
+    assert rec["ms_per_step"] * 5e-3 >= max(r["elapsed_s"] for r in pr) - 1e-6
+    want = 2048 * 2048 * 1 * 2 * 5 / (rec["ms_per_step"] * 5e-3) / 1e9
+    assert abs(rec["value"] - want) / want < 1e-3
+    assert rec["cpu_baseline"] is None and "also" not in rec                  # N = 1 only
+
+
+def test_bench_same_line_under_the_torchrun_launcher():
+    out = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "2048", "--no-cpu-baseline"],
+                 launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port())])
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and len(rec["per_rank"]) == 2 and rec["config"]["rank_sync"] == "file"
+
+
+def test_bench_rehearsal_switch_and_refusals():
+    # more ranks than devices: refused without --oversubscribe, shared round-robin with it
+    out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "0", "--size", "2048", "--no-cpu-baseline"],
+                 extra_env={"GCN10_FAKE_DEVICES": "1"})
+    assert out.returncode != 0
+    out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "0", "--size", "2048", "--no-cpu-baseline",
+                  "--oversubscribe"], extra_env={"GCN10_FAKE_DEVICES": "1"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert [r["device"] for r in rec["per_rank"]] == [0, 0]
+    # a launcher's world size that does not match --gpus is refused
+    out = _bench(["--gpus", "2", "--no-cpu-baseline"], extra_env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert out.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in (out.stderr + out.stdout)
+
+
+def test_bench_single_rank_with_the_stand_in_engine():
+    out = _bench(["--steps", "3", "--warmup", "1", "--size", "2048", "--no-cpu-baseline"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and len(rec["per_rank"]) == 1
+    assert rec["roofline"]["copy_ceiling"]["kernel"] == "stream_copy_kernel"
+    assert rec["also"]["workload"].startswith("config4") and "round1_style_ms_per_launch" in rec["also"]

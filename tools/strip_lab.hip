@@ -83,7 +83,7 @@ struct Trip {
     uint32_t i0[ILP];
 };
 
-template <int LUTK, int ILP, int THREADS, int DIAG>
+template <int LUTK, int ILP, int THREADS, int DIAG, int NTM>
 __device__ __forceinline__ void issue(const P &p, uint32_t trip, uint32_t lane16, uint32_t wave, Trip<ILP> &t)
 {
     uint32_t x[ILP], r0[ILP], r1[ILP], wb[ILP];
@@ -100,7 +100,8 @@ __device__ __forceinline__ void issue(const P &p, uint32_t trip, uint32_t lane16
     for (int u = 0; u < ILP; u++) {
         t.i0[u] = wb[u] + lane16;
         const bool live = t.i0[u] < p.nvec * 16u;
-        t.e[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p.esa + (live ? t.i0[u] : 0u)));
+        const u32x4 *pe = reinterpret_cast<const u32x4 *>(p.esa + (live ? t.i0[u] : 0u));
+        t.e[u] = (NTM & 1) ? __builtin_nontemporal_load(pe) : *pe;
     }
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
@@ -137,7 +138,7 @@ __device__ __forceinline__ void issue(const P &p, uint32_t trip, uint32_t lane16
     }
 }
 
-template <int LUTK, int ILP, int DIAG>
+template <int LUTK, int ILP, int DIAG, int NTM>
 __device__ __forceinline__ void finish(const P &p, const uint8_t *lut, uint32_t lane_rep, const Trip<ILP> &t)
 {
 #pragma unroll
@@ -170,12 +171,16 @@ __device__ __forceinline__ void finish(const P &p, const uint8_t *lut, uint32_t 
                 v[j] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
             }
         }
-        if (t.i0[u] < p.nvec * 16u)
-            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p.out + t.i0[u]));
+        if (t.i0[u] < p.nvec * 16u) {
+            if (NTM & 2)
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p.out + t.i0[u]));
+            else
+                *reinterpret_cast<u32x4 *>(p.out + t.i0[u]) = v;
+        }
     }
 }
 
-template <int LUTK, int ILP, bool PF, int THREADS, int DIAG>
+template <int LUTK, int ILP, bool PF, int THREADS, int DIAG, int MAP = 1, int NTM = 3>
 __global__ __launch_bounds__(THREADS) void lab_kernel(const P p)
 {
     constexpr int kLutBytes = LUTK == 2 ? kLutB : ((kLutA + 15) & ~15);
@@ -197,35 +202,35 @@ __global__ __launch_bounds__(THREADS) void lab_kernel(const P p)
     const uint32_t nb = gridDim.x, b = blockIdx.x;
     const uint32_t per = (p.ntrips + 7u) / 8u;
     const uint32_t lo = (b & 7u) * per;
-    const uint32_t end = lo + per < p.ntrips ? lo + per : p.ntrips;
-    const uint32_t step = nb / 8u;
-    uint32_t trip = lo + (b >> 3);
+    const uint32_t end = MAP ? (lo + per < p.ntrips ? lo + per : p.ntrips) : p.ntrips;
+    const uint32_t step = MAP ? nb / 8u : nb;
+    uint32_t trip = MAP ? lo + (b >> 3) : b;
 
     if (!PF) {
         for (; trip < end; trip += step) {
             Trip<ILP> t;
-            issue<LUTK, ILP, THREADS, DIAG>(p, trip, lane16, wave, t);
-            finish<LUTK, ILP, DIAG>(p, lut, lane_rep, t);
+            issue<LUTK, ILP, THREADS, DIAG, NTM>(p, trip, lane16, wave, t);
+            finish<LUTK, ILP, DIAG, NTM>(p, lut, lane_rep, t);
         }
     }
     else if (trip < end) {
         Trip<ILP> ta, tb;
-        issue<LUTK, ILP, THREADS, DIAG>(p, trip, lane16, wave, ta);
+        issue<LUTK, ILP, THREADS, DIAG, NTM>(p, trip, lane16, wave, ta);
         for (;;) {
             trip += step;
             if (trip >= end) {
-                finish<LUTK, ILP, DIAG>(p, lut, lane_rep, ta);
+                finish<LUTK, ILP, DIAG, NTM>(p, lut, lane_rep, ta);
                 break;
             }
-            issue<LUTK, ILP, THREADS, DIAG>(p, trip, lane16, wave, tb);
-            finish<LUTK, ILP, DIAG>(p, lut, lane_rep, ta);
+            issue<LUTK, ILP, THREADS, DIAG, NTM>(p, trip, lane16, wave, tb);
+            finish<LUTK, ILP, DIAG, NTM>(p, lut, lane_rep, ta);
             trip += step;
             if (trip >= end) {
-                finish<LUTK, ILP, DIAG>(p, lut, lane_rep, tb);
+                finish<LUTK, ILP, DIAG, NTM>(p, lut, lane_rep, tb);
                 break;
             }
-            issue<LUTK, ILP, THREADS, DIAG>(p, trip, lane16, wave, ta);
-            finish<LUTK, ILP, DIAG>(p, lut, lane_rep, tb);
+            issue<LUTK, ILP, THREADS, DIAG, NTM>(p, trip, lane16, wave, ta);
+            finish<LUTK, ILP, DIAG, NTM>(p, lut, lane_rep, tb);
         }
     }
     // the last npix % 16 pixels, byte-wise
@@ -245,13 +250,14 @@ __global__ __launch_bounds__(THREADS) void lab_kernel(const P p)
 // ---------------------------------------------------------------------------------------------
 // plain 1R:1W copy of the same launch shape (XCD slabs)
 // ---------------------------------------------------------------------------------------------
-template <int UN, int THREADS>
+template <int UN, int THREADS, int MAP = 1>
 __global__ __launch_bounds__(THREADS) void copy_kernel(const u32x4 *in, u32x4 *out, size_t nvec)
 {
     const size_t nchunk = (nvec + THREADS * UN - 1) / (THREADS * UN);
     const size_t per = (nchunk + 7) / 8, xcd = blockIdx.x & 7;
-    size_t c = xcd * per + (blockIdx.x >> 3);
-    const size_t cend = (xcd + 1) * per < nchunk ? (xcd + 1) * per : nchunk, cstep = gridDim.x / 8;
+    size_t c = MAP ? xcd * per + (blockIdx.x >> 3) : blockIdx.x;
+    const size_t cend = MAP ? ((xcd + 1) * per < nchunk ? (xcd + 1) * per : nchunk) : nchunk;
+    const size_t cstep = MAP ? gridDim.x / 8 : gridDim.x;
     for (; c < cend; c += cstep) {
         u32x4 v[UN];
         size_t idx[UN];
@@ -268,15 +274,80 @@ __global__ __launch_bounds__(THREADS) void copy_kernel(const u32x4 *in, u32x4 *o
 }
 
 // ---------------------------------------------------------------------------------------------
+// host side: every variant is a closure that launches one kernel with the events attached to the
+// dispatch; variants are timed in interleaved rounds (A B C ... A B C ...) so that drift of the box
+// (clocks, temperature) falls on all of them alike.
+// ---------------------------------------------------------------------------------------------
+#include <functional>
+#include <string>
+
+struct Variant {
+    std::string name;
+    int blocks, threads;
+    double bytes;
+    std::function<void(hipEvent_t, hipEvent_t)> launch;
+    uint8_t *check;             // raster to compare with the reference after the first launch, or null
+    std::vector<float> ms;
+    long long bad = -1;
+};
+
 struct Lab {
-    P pA, pB;           // nibble-coded soil / replicated-LUT soil
+    P pA, pB;
     uint8_t *ref;
+    uint8_t *outs[3];
     unsigned long long *d_count;
-    int reps;
     int cus;
     hipStream_t s;
-    std::vector<hipEvent_t> ev0, ev1;
+    std::vector<Variant> v;
 };
+
+template <int LUTK, int ILP, bool PF, int THREADS, int DIAG, int MAP = 1, int NTM = 3>
+static void add_variant(Lab &L, int wg_per_cu, int out_idx = 0)
+{
+    P p = LUTK == 2 ? L.pB : L.pA;
+    p.out = L.outs[out_idx];
+    const uint32_t trip_px = THREADS * 16 * ILP;
+    p.ntrips = (p.npix + trip_px - 1) / trip_px;
+    int blocks = L.cus * wg_per_cu;
+    blocks -= blocks % 8;
+    char name[160];
+    snprintf(name, sizeof name, "lut%d_ilp%d_pf%d_t%d_diag%d_map%d_nt%d_wg%d_out%d", LUTK, ILP, (int)PF, THREADS, DIAG, MAP,
+             NTM, wg_per_cu, out_idx);
+    Variant v;
+    v.name = name; v.blocks = blocks; v.threads = THREADS;
+    v.bytes = 2.0 * p.npix + 1440.0 * 1440.0 + 4.0 * (p.W + p.rows);
+    v.check = DIAG ? nullptr : p.out;
+    hipStream_t s = L.s;
+    v.launch = [p, blocks, s](hipEvent_t a, hipEvent_t b) {
+        P pp = p;
+        void *args[] = {&pp};
+        CK(hipExtLaunchKernel(reinterpret_cast<const void *>(lab_kernel<LUTK, ILP, PF, THREADS, DIAG, MAP, NTM>), dim3(blocks),
+                              dim3(THREADS), args, 0, s, a, b, 0));
+    };
+    L.v.push_back(v);
+}
+
+template <int UN, int THREADS, int MAP = 1>
+static void add_copy(Lab &L, int wg_per_cu)
+{
+    int blocks = L.cus * wg_per_cu;
+    blocks -= blocks % 8;
+    char name[64];
+    snprintf(name, sizeof name, "copy_un%d_t%d_map%d_wg%d", UN, THREADS, MAP, wg_per_cu);
+    const u32x4 *in = (const u32x4 *)L.pA.esa;
+    u32x4 *out = (u32x4 *)L.outs[0];
+    size_t nvec = L.pA.npix / 16;
+    Variant v;
+    v.name = name; v.blocks = blocks; v.threads = THREADS; v.bytes = 2.0 * L.pA.npix; v.check = nullptr;
+    hipStream_t s = L.s;
+    v.launch = [in, out, nvec, blocks, s](hipEvent_t a, hipEvent_t b) {
+        const u32x4 *i_ = in; u32x4 *o_ = out; size_t n_ = nvec;
+        void *args[] = {&i_, &o_, &n_};
+        CK(hipExtLaunchKernel(reinterpret_cast<const void *>(copy_kernel<UN, THREADS, MAP>), dim3(blocks), dim3(THREADS), args, 0,
+                              s, a, b, 0));
+    };
+    L.v.push_back(v);
+}
 
 static double median(std::vector<float> v)
 {
@@ -284,76 +355,55 @@ static double median(std::vector<float> v)
     return v[v.size() / 2];
 }
 
-template <typename F>
-static void time_launches(Lab &L, const char *name, int blocks, int threads, double bytes, F launch, uint8_t *out_to_check)
+static void run_all(Lab &L, int rounds, int per_round)
 {
-    for (int w = 0; w < 3; w++)
-        launch(nullptr, nullptr);
-    CK(hipStreamSynchronize(L.s));
-    for (int r = 0; r < L.reps; r++)
-        launch(L.ev0[r], L.ev1[r]);
-    CK(hipStreamSynchronize(L.s));
-    std::vector<float> ms(L.reps);
-    double sum = 0;
-    for (int r = 0; r < L.reps; r++) {
-        CK(hipEventElapsedTime(&ms[r], L.ev0[r], L.ev1[r]));
-        sum += ms[r];
+    std::vector<hipEvent_t> e0(per_round), e1(per_round);
+    for (int i = 0; i < per_round; i++) { CK(hipEventCreate(&e0[i])); CK(hipEventCreate(&e1[i])); }
+    // first launch of every variant: correctness
+    for (auto &v : L.v) {
+        if (v.check)
+            CK(hipMemsetAsync(v.check, 0x5a, L.pA.npix, L.s));
+        v.launch(nullptr, nullptr);
+        if (v.check) {
+            CK(hipMemsetAsync(L.d_count, 0, 8, L.s));
+            hipLaunchKernelGGL(diff_kernel, dim3(2048), dim3(256), 0, L.s, (const u32x4 *)v.check, (const u32x4 *)L.ref,
+                               (size_t)L.pA.npix / 16, L.d_count);
+            unsigned long long c;
+            CK(hipMemcpyAsync(&c, L.d_count, 8, hipMemcpyDeviceToHost, L.s));
+            CK(hipStreamSynchronize(L.s));
+            v.bad = (long long)c;
+        }
     }
-    float span = 0;
-    CK(hipEventElapsedTime(&span, L.ev0[0], L.ev1[L.reps - 1]));
-    long long bad = -1;
-    if (out_to_check) {
-        CK(hipMemsetAsync(L.d_count, 0, 8, L.s));
-        hipLaunchKernelGGL(diff_kernel, dim3(2048), dim3(256), 0, L.s, (const u32x4 *)out_to_check, (const u32x4 *)L.ref,
-                           (size_t)L.pA.npix / 16, L.d_count);
-        unsigned long long c;
-        CK(hipMemcpyAsync(&c, L.d_count, 8, hipMemcpyDeviceToHost, L.s));
-        CK(hipStreamSynchronize(L.s));
-        bad = (long long)c;
+    CK(hipStreamSynchronize(L.s));
+    for (int r = 0; r < rounds; r++) {
+        for (auto &v : L.v) {
+            v.launch(nullptr, nullptr);                 // one untimed launch after the switch of kernels
+            for (int i = 0; i < per_round; i++)
+                v.launch(e0[i], e1[i]);
+            CK(hipStreamSynchronize(L.s));
+            for (int i = 0; i < per_round; i++) {
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0[i], e1[i]));
+                v.ms.push_back(ms);
+            }
+        }
     }
-    const double med = median(ms), avg = sum / L.reps, mn = *std::min_element(ms.begin(), ms.end());
-    printf("{\"variant\": \"%s\", \"blocks\": %d, \"threads\": %d, \"avg_ms\": %.4f, \"median_ms\": %.4f, \"min_ms\": %.4f, "
-           "\"span_ms_per_launch\": %.4f, \"GBps_avg\": %.1f, \"frac_avg\": %.4f, \"bad_vectors\": %lld}\n",
-           name, blocks, threads, avg, med, mn, span / L.reps, bytes / avg / 1e6, bytes / avg / 1e6 / 8000.0, bad);
+    for (auto &v : L.v) {
+        double sum = 0;
+        for (float m : v.ms) sum += m;
+        const double avg = sum / v.ms.size(), med = median(v.ms), mn = *std::min_element(v.ms.begin(), v.ms.end());
+        printf("{\"variant\": \"%s\", \"blocks\": %d, \"threads\": %d, \"n\": %zu, \"avg_ms\": %.4f, \"median_ms\": %.4f, "
+               "\"min_ms\": %.4f, \"GBps_median\": %.1f, \"frac_median\": %.4f, \"bad_vectors\": %lld, \"round_avgs\": [",
+               v.name.c_str(), v.blocks, v.threads, v.ms.size(), avg, med, mn, v.bytes / med / 1e6, v.bytes / med / 1e6 / 8000.0,
+               v.bad);
+        for (int r = 0; r < rounds; r++) {
+            double rs = 0;
+            for (int i = 0; i < per_round; i++) rs += v.ms[r * per_round + i];
+            printf("%s%.4f", r ? ", " : "", rs / per_round);
+        }
+        printf("]}\n");
+    }
     fflush(stdout);
-}
-
-template <int LUTK, int ILP, bool PF, int THREADS, int DIAG>
-static void run_variant(Lab &L, int wg_per_cu)
-{
-    P p = LUTK == 2 ? L.pB : L.pA;
-    const uint32_t trip_px = THREADS * 16 * ILP;
-    p.ntrips = (p.npix + trip_px - 1) / trip_px;
-    int blocks = L.cus * wg_per_cu;
-    blocks -= blocks % 8;
-    char name[128];
-    snprintf(name, sizeof name, "lut%d_ilp%d_pf%d_t%d_diag%d_wg%d", LUTK, ILP, (int)PF, THREADS, DIAG, wg_per_cu);
-    CK(hipMemsetAsync(p.out, 0x5a, p.npix, L.s));
-    void *args[] = {&p};
-    auto launch = [&](hipEvent_t a, hipEvent_t b) {
-        CK(hipExtLaunchKernel(reinterpret_cast<const void *>(lab_kernel<LUTK, ILP, PF, THREADS, DIAG>), dim3(blocks),
-                              dim3(THREADS), args, 0, L.s, a, b, 0));
-    };
-    const double bytes = 2.0 * p.npix + 1440.0 * 1440.0 + 4.0 * (p.W + p.rows);
-    time_launches(L, name, blocks, THREADS, bytes, launch, DIAG ? nullptr : p.out);
-}
-
-template <int UN, int THREADS>
-static void run_copy(Lab &L, int wg_per_cu)
-{
-    int blocks = L.cus * wg_per_cu;
-    blocks -= blocks % 8;
-    char name[64];
-    snprintf(name, sizeof name, "copy_un%d_t%d_wg%d", UN, THREADS, wg_per_cu);
-    const u32x4 *in = (const u32x4 *)L.pA.esa;
-    u32x4 *out = (u32x4 *)L.pA.out;
-    size_t nvec = L.pA.npix / 16;
-    void *args[] = {&in, &out, &nvec};
-    auto launch = [&](hipEvent_t a, hipEvent_t b) {
-        CK(hipExtLaunchKernel(reinterpret_cast<const void *>(copy_kernel<UN, THREADS>), dim3(blocks), dim3(THREADS), args, 0,
-                              L.s, a, b, 0));
-    };
-    time_launches(L, name, blocks, THREADS, 2.0 * L.pA.npix, launch, nullptr);
 }
 
 static uint32_t lcg(uint32_t &s) { s = s * 1664525u + 1013904223u; return s >> 8; }
@@ -362,15 +412,14 @@ int main(int argc, char **argv)
 {
     const uint32_t W = argc > 1 ? atoi(argv[1]) : 36000, rows = argc > 2 ? atoi(argv[2]) : 36000;
     Lab L;
-    L.reps = argc > 3 ? atoi(argv[3]) : 20;
-    const char *only = argc > 4 ? argv[4] : "";
+    const int rounds = argc > 3 ? atoi(argv[3]) : 6;
+    const int per_round = argc > 4 ? atoi(argv[4]) : 6;
+    const char *set = argc > 5 ? argv[5] : "main";
     const uint32_t npix = W * rows, hs = 1440;
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     L.cus = prop.multiProcessorCount;
     CK(hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking));
-    L.ev0.resize(L.reps); L.ev1.resize(L.reps);
-    for (int r = 0; r < L.reps; r++) { CK(hipEventCreate(&L.ev0[r])); CK(hipEventCreate(&L.ev1[r])); }
 
     // ---- synthetic block: classes and probabilities of bench.py's "iid" pattern ----
     static const uint8_t classes[12] = {0, 10, 20, 30, 40, 50, 60, 70, 80, 90, 95, 100};
@@ -405,9 +454,10 @@ int main(int argc, char **argv)
                 lutB[(lc << 8) | (s & 3) | (rep << 2) | ((s >> 2) << 7)] = v;
         }
 
-    uint8_t *d_esa, *d_hxA, *d_hxB, *d_lutA, *d_lutB, *d_out, *d_ref;
+    uint8_t *d_esa, *d_hxA, *d_hxB, *d_lutA, *d_lutB, *d_ref;
     int32_t *d_cj;
-    CK(hipMalloc((void **)&d_esa, npix)); CK(hipMalloc((void **)&d_out, npix)); CK(hipMalloc((void **)&d_ref, npix));
+    CK(hipMalloc((void **)&d_esa, npix)); CK(hipMalloc((void **)&d_ref, npix));
+    for (int i = 0; i < 3; i++) CK(hipMalloc((void **)&L.outs[i], npix));
     CK(hipMalloc((void **)&d_hxA, hxA.size())); CK(hipMalloc((void **)&d_hxB, hxB.size()));
     CK(hipMalloc((void **)&d_lutA, lutA.size())); CK(hipMalloc((void **)&d_lutB, lutB.size()));
     CK(hipMalloc((void **)&d_cj, rows * 4)); CK(hipMalloc((void **)&L.d_count, 8));
@@ -419,66 +469,41 @@ int main(int argc, char **argv)
     CK(hipMemcpy(d_cj, cj.data(), rows * 4, hipMemcpyHostToDevice));
     L.ref = d_ref;
     P base{};
-    base.esa = d_esa; base.cj = d_cj; base.out = d_out; base.W = W; base.rows = rows; base.npix = npix; base.nvec = npix / 16;
+    base.esa = d_esa; base.cj = d_cj; base.out = L.outs[0]; base.W = W; base.rows = rows; base.npix = npix; base.nvec = npix / 16;
     base.hx_stride = stride; base.hx_rows = hs;
     L.pA = base; L.pA.hx = d_hxA + 16; L.pA.lut = d_lutA;
     L.pB = base; L.pB.hx = d_hxB + 16; L.pB.lut = d_lutB;
     hipLaunchKernelGGL(ref_kernel, dim3(4096), dim3(256), 0, L.s, d_esa, d_hxA + 16, stride, d_cj, d_lutA, d_ref, W, npix);
     CK(hipStreamSynchronize(L.s));
-    // the tail pixels of the variants are compared too: diff covers npix/16 vectors only, so check the tail on the host
-    printf("{\"lab\": \"strip\", \"W\": %u, \"rows\": %u, \"cus\": %d, \"reps\": %d}\n", W, rows, L.cus, L.reps);
+    printf("{\"lab\": \"strip\", \"W\": %u, \"rows\": %u, \"cus\": %d, \"rounds\": %d, \"per_round\": %d, \"set\": \"%s\", "
+           "\"out_ptrs\": [\"%p\", \"%p\", \"%p\"], \"esa_ptr\": \"%p\"}\n",
+           W, rows, L.cus, rounds, per_round, set, (void *)L.outs[0], (void *)L.outs[1], (void *)L.outs[2], (void *)d_esa);
 
-    const bool quick = !strcmp(only, "quick");
-    // ---- ramp: does the launch time drift over the first launches after an idle period? ----
-    if (!quick) {
-        P p = L.pA;
-        p.ntrips = (npix + 256 * 16 * 2 - 1) / (256 * 16 * 2);
-        void *args[] = {&p};
-        const int n = 200;
-        std::vector<hipEvent_t> a(n), b(n);
-        for (int i = 0; i < n; i++) { CK(hipEventCreate(&a[i])); CK(hipEventCreate(&b[i])); }
-        for (int i = 0; i < n; i++)
-            CK(hipExtLaunchKernel(reinterpret_cast<const void *>(lab_kernel<0, 2, false, 256, 0>), dim3(2048), dim3(256), args,
-                                  0, L.s, a[i], b[i], 0));
-        CK(hipStreamSynchronize(L.s));
-        printf("{\"ramp_ms\": [");
-        for (int i = 0; i < n; i++) {
-            float ms; CK(hipEventElapsedTime(&ms, a[i], b[i]));
-            if (i < 12 || i % 10 == 0) printf("%s[%d, %.4f]", i ? ", " : "", i, ms);
-        }
-        printf("]}\n");
-        fflush(stdout);
+    if (!strcmp(set, "main")) {
+        add_copy<2, 256, 1>(L, 8); add_copy<2, 256, 0>(L, 8); add_copy<2, 512, 1>(L, 4); add_copy<2, 256, 1>(L, 16);
+        add_copy<4, 256, 0>(L, 16);
+        add_variant<0, 2, true, 256, 0>(L, 8);              // run 1's best
+        add_variant<0, 2, true, 256, 0>(L, 16);
+        add_variant<0, 2, true, 256, 0, 0>(L, 8);           // grid-stride instead of XCD slabs
+        add_variant<0, 2, true, 256, 0, 0>(L, 16);
+        add_variant<0, 2, false, 256, 0>(L, 8);
+        add_variant<0, 4, false, 256, 0, 0>(L, 16);
+        add_variant<0, 4, false, 256, 0, 1>(L, 8);
+        add_variant<0, 2, true, 256, 0, 1, 2>(L, 8);        // landcover loads with the default policy
+        add_variant<0, 2, true, 256, 0, 1, 1>(L, 8);        // raster stores with the default policy
+        add_variant<0, 2, true, 256, 0, 1, 3>(L, 8, 1);     // the same kernel into two other allocations
+        add_variant<0, 2, true, 256, 0, 1, 3>(L, 8, 2);
+        add_variant<0, 2, true, 256, 1>(L, 8);              // timing only: no gather / no soil load / neither
+        add_variant<0, 2, true, 256, 2>(L, 8);
+        add_variant<0, 2, true, 256, 3>(L, 8);
     }
-
-    // ---- copy ceilings ----
-    run_copy<2, 256>(L, 4); run_copy<2, 256>(L, 8); run_copy<4, 256>(L, 8); run_copy<1, 256>(L, 8);
-    run_copy<2, 1024>(L, 2); run_copy<2, 512>(L, 4); run_copy<4, 256>(L, 4);
-
-    // ---- today's shape, then one change at a time ----
-    run_variant<0, 2, false, 256, 0>(L, 8);
-    run_variant<0, 2, true, 256, 0>(L, 8);
-    run_variant<0, 1, true, 256, 0>(L, 8);
-    run_variant<0, 4, false, 256, 0>(L, 8);
-    run_variant<0, 4, true, 256, 0>(L, 8);
-    run_variant<0, 2, true, 256, 0>(L, 4);
-    run_variant<0, 2, true, 512, 0>(L, 4);
-    run_variant<0, 2, true, 1024, 0>(L, 2);
-    // replicated LUT (64 KB of LDS: two workgroups per CU)
-    run_variant<2, 2, false, 1024, 0>(L, 2);
-    run_variant<2, 2, true, 1024, 0>(L, 2);
-    run_variant<2, 1, true, 1024, 0>(L, 2);
-    run_variant<2, 4, true, 1024, 0>(L, 2);
-    run_variant<2, 2, true, 512, 0>(L, 2);
-    run_variant<2, 4, true, 512, 0>(L, 2);
-    run_variant<2, 4, false, 512, 0>(L, 2);
-    // decomposition (timing only)
-    run_variant<0, 2, true, 256, 1>(L, 8);
-    run_variant<0, 2, true, 256, 2>(L, 8);
-    run_variant<0, 2, true, 256, 3>(L, 8);
-    run_variant<2, 2, true, 1024, 1>(L, 2);
-    run_variant<2, 2, true, 1024, 2>(L, 2);
-    run_variant<2, 2, true, 1024, 3>(L, 2);
-    // copy again at the end (drift check)
-    run_copy<2, 256>(L, 4); run_copy<4, 256>(L, 8);
+    else {      // "check": correctness of the odd-width paths
+        add_variant<0, 2, true, 256, 0>(L, 8);
+        add_variant<0, 1, true, 256, 0>(L, 8);
+        add_variant<0, 2, false, 256, 0, 0>(L, 8);
+        add_variant<0, 4, false, 256, 0>(L, 8);
+        add_variant<2, 2, true, 1024, 0>(L, 2);
+    }
+    run_all(L, rounds, per_round);
     return 0;
 }

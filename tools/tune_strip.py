@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """Times the strip-kernel launch variants on one resident 36000^2 block (GPU only).
 
-    python tools/tune_strip.py [--size 36000] [--reps 10] > gpurun_out/tune.json
+    python tools/tune_strip.py [--size 36000] [--rounds 5] [--per-round 5] > gpurun_out/tune.jsonl
 
-Every variant's output is compared (SHA-256 of raster 7 / all selected rasters'
-first MB) with the default variant's so a faster-but-wrong variant is flagged.
+Variants are timed in interleaved rounds (A B C ... A B C ...), every launch with events carried by
+its own dispatch, and the plain 1R:1W copy (gcn10_gpu_stream_copy) is one of the variants: drift of
+the box falls on all of them alike, and every figure can be read against the same run's copy.
+Every variant's output is compared (SHA-256 of the first and last MB of its first rasters) with the
+first variant's, so a faster-but-wrong variant is flagged.
 """
 import argparse
 import hashlib
@@ -25,9 +28,10 @@ from gcn10_amd import gpu, host  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=36000)
-    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--per-round", type=int, default=5)
     ap.add_argument("--pattern", default="iid")
-    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--workloads", default="config2,config4,config4-drained")
     a = ap.parse_args()
     size = a.size
     eng = gpu.Engine(0)
@@ -39,7 +43,7 @@ def main():
     d_esa, d_coarse, d_ci, d_cj = eng.upload(esa), eng.upload(coarse), eng.upload(ci), eng.upload(cj)
     outs = [eng.alloc(npix) for _ in range(18)]
     ptrs = [o.ptr for o in outs]
-    e0, e1 = eng.event_create(), eng.event_create()
+    ev = [(eng.event_create(), eng.event_create()) for _ in range(a.per_round)]
     eng.prepare_tile(d_coarse.ptr, hs, hs, d_ci.ptr, size)
     eng.sync()
 
@@ -50,59 +54,64 @@ def main():
             h.update(eng.download(outs[r].at(npix - (1 << 20)), (1 << 20,)).tobytes())
         return h.hexdigest()[:16]
 
-    def time_it(cond_mask, table_mask, rasters):
-        for r in rasters:
-            eng.memset(outs[r].ptr, 0, 1 << 20)
-        eng.cn_strip(d_esa.ptr, size, size, d_cj.ptr, cond_mask, table_mask, ptrs)
-        eng.sync()
-        eng.event_record(e0)
-        for _ in range(a.reps):
-            eng.cn_strip(d_esa.ptr, size, size, d_cj.ptr, cond_mask, table_mask, ptrs)
-        eng.event_record(e1)
-        eng.sync()
-        return eng.elapsed_ms(e0, e1) / a.reps
-
-    results = []
-    # prepare_tile timing
-    eng.event_record(e0)
-    for _ in range(a.reps):
-        eng.prepare_tile(d_coarse.ptr, hs, hs, d_ci.ptr, size)
-    eng.event_record(e1)
-    eng.sync()
-    results.append({"kernel": "expand_x_codes", "ms": eng.elapsed_ms(e0, e1) / a.reps})
-    print(json.dumps(results[-1]), flush=True)
-
-    workloads = [("config2", 1, 1 << 7, [7], "ilp1", [1, 2, 4]),
-                 ("config4", 3, 0x1FF, list(range(18)), "ilp16", [1, 2]),
-                 ("config4-drained", 1, 0x1FF, list(range(9)), "ilp16", [1, 2])]
-    ref = {}
-    for name, cm, tm, rasters, ilp_key, ilps in workloads:
+    specs = {"config2": (1, 1 << 7, [7], "ilp1", [1, 2, 4], [8, 16]),
+             "config4": (3, 0x1FF, list(range(18)), "ilp16", [1, 2], [4, 8, 16]),
+             "config4-drained": (1, 0x1FF, list(range(9)), "ilp16", [1, 2], [4, 8, 16])}
+    nb = npix - npix % 16
+    for name in a.workloads.split(","):
+        cm, tm, rasters, ilp_key, ilps, grids = specs[name]
         alg = gpu.strip_algorithmic_bytes(size, size, hs, hs, cm, tm)
-        grids = [4, 8, 16] if not a.quick else [8, 16]
-        for ilp, nt, xcd, bpc, pf in itertools.product(ilps, [1, 0], [1, 0], grids, [1, 0]):
-            if a.quick and (nt == 0 or xcd == 0):
-                continue
+        variants = [{"copy": True, "blocks_per_cu": 8}, {"copy": True, "blocks_per_cu": 16}]
+        for ilp, pf, xcd, bpc in itertools.product(ilps, [1, 0], [1, 0], grids):
             if pf and ilp > 2:
                 continue            # pipelined variants exist for 1 and 2 chunks per trip
-            eng.set_option("prefetch", pf)
-            eng.set_option(ilp_key, ilp)
-            eng.set_option("nontemporal", nt)
-            eng.set_option("xcd_slabs", xcd)
-            eng.set_option("grid_blocks_per_cu", bpc)
-            ms = time_it(cm, tm, rasters)
+            variants.append({"ilp": ilp, "pf": pf, "nt": 1, "xcd_slabs": xcd, "blocks_per_cu": bpc})
+        variants.append({"ilp": ilps[-1] if name != "config4" else 1, "pf": 1 if name != "config2" else 0, "nt": 0,
+                         "xcd_slabs": 1, "blocks_per_cu": 8})
+
+        def launch(v, timed=None):
+            eng.set_option("grid_blocks_per_cu", v["blocks_per_cu"])
+            if timed is not None:
+                eng.time_next_strip(*timed)
+            if v.get("copy"):
+                eng.stream_copy(d_esa.ptr, outs[17].ptr, nb)
+                return
+            eng.set_option("prefetch", v["pf"])
+            eng.set_option(ilp_key, v["ilp"])
+            eng.set_option("nontemporal", v["nt"])
+            eng.set_option("xcd_slabs", v["xcd_slabs"])
+            eng.cn_strip(d_esa.ptr, size, size, d_cj.ptr, cm, tm, ptrs)
+
+        ref = None
+        for v in variants:
+            v["ms"] = []
+            if v.get("copy"):
+                v["ok"] = True
+                continue
+            for r in rasters[:3]:
+                eng.memset(outs[r].ptr, 0, 1 << 20)
+            launch(v)
+            eng.sync()
             d = digest(rasters[:3])
-            ref.setdefault(name, d)
-            rec = {"workload": name, "ilp": ilp, "pf": pf, "nt": nt, "xcd_slabs": xcd, "blocks_per_cu": bpc,
-                   "ms": round(ms, 4), "GBps": round(alg / ms / 1e6, 1),
-                   "frac": round(alg / ms / 1e6 / 8000, 4), "ok": d == ref[name]}
-            results.append(rec)
+            ref = ref or d
+            v["ok"] = d == ref
+            v["kernel"] = eng.last_kernel_name()
+        for _ in range(a.rounds):
+            for v in variants:
+                launch(v)                           # one untimed launch after the switch
+                for i in range(a.per_round):
+                    launch(v, ev[i])
+                eng.sync()
+                v["ms"] += [eng.elapsed_ms(*ev[i]) for i in range(a.per_round)]
+        for v in variants:
+            ms = np.array(v.pop("ms"))
+            by = 2 * nb if v.get("copy") else alg
+            rec = dict(workload=name, **v, n=len(ms), median_ms=round(float(np.median(ms)), 4),
+                       avg_ms=round(float(ms.mean()), 4), min_ms=round(float(ms.min()), 4),
+                       GBps_median=round(by / float(np.median(ms)) / 1e6, 1),
+                       frac_median=round(by / float(np.median(ms)) / 1e6 / 8000, 4))
             print(json.dumps(rec), flush=True)
-    best = {}
-    for r in results:
-        if "workload" in r and r["ok"]:
-            if r["workload"] not in best or r["ms"] < best[r["workload"]]["ms"]:
-                best[r["workload"]] = r
-    print(json.dumps({"best": best}))
+    eng.set_option("defaults", 0)
 
 
 if __name__ == "__main__":
