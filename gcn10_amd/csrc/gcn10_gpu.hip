@@ -777,9 +777,9 @@ namespace {
 
 // Memory-bound streaming grid: a few workgroups per CU, each looping over
 // chunks; a multiple of 8 so every XCD gets the same number.
-uint32_t stream_grid(const gcn10_gpu_ctx *ctx, uint64_t nchunks)
+uint32_t stream_grid(const gcn10_gpu_ctx *ctx, uint64_t nchunks, int blocks_per_cu = 0)
 {
-    uint64_t cap = (uint64_t)ctx->n_cus * ctx->grid_blocks_per_cu;
+    uint64_t cap = (uint64_t)ctx->n_cus * (blocks_per_cu > 0 ? blocks_per_cu : ctx->grid_blocks_per_cu);
     cap -= cap % 8u;
     if (cap < 8)
         cap = 8;
@@ -1362,7 +1362,9 @@ int gcn10_gpu_cn_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, int rows,
         const bool all = table_mask == 0x1ffu;
         // 0 = by the number of store streams: two chunks per trip up to nine rasters, one beyond
         const int n_streams = popcount(cond_mask) * popcount(table_mask);
-        const int ilp = single ? ctx->ilp1 : (ctx->ilp16 > 0 ? ctx->ilp16 : (n_streams > 9 ? 1 : 2));
+        const bool tuned = single && ctx->single.set;
+        const int ilp = tuned ? ctx->single.ilp
+                              : single ? ctx->ilp1 : (ctx->ilp16 > 0 ? ctx->ilp16 : (n_streams > 9 ? 1 : 2));
         const bool nt = ctx->nontemporal != 0;
         if (single) {
             p.single_k = (uint32_t)__builtin_ctz(table_mask);
@@ -1372,8 +1374,10 @@ int gcn10_gpu_cn_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, int rows,
             p.lut = ctx->d_lut16;
         }
         p.nchunks = (p.nchunks + (uint32_t)ilp - 1) / (uint32_t)ilp;    // groups of ILP sub-chunks
-        const uint32_t grid = stream_grid(ctx, p.nchunks);
-        const bool pf = ctx->prefetch != 0 && ilp <= 2;
+        const uint32_t grid = stream_grid(ctx, p.nchunks, tuned ? ctx->single.grid_blocks_per_cu : 0);
+        const bool pf = (tuned ? ctx->single.prefetch : ctx->prefetch) != 0 && ilp <= 2;
+        if (tuned)
+            p.xcd_slabs = (uint32_t)ctx->single.xcd_slabs;
         strip_kernel_t fn = pick_strip_kernel(single, cond_mask, all, ilp, nt, pf);
         if (!fn)
             return fail(GCN10_E_INVAL, "gcn10_gpu_cn_strip: no kernel for ilp=%d", ilp);
@@ -1424,13 +1428,16 @@ int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value)
         ctx->prefetch = fresh.prefetch;
         ctx->deflate_wave_codes = fresh.deflate_wave_codes;
         ctx->fused_diag = fresh.fused_diag;
+        ctx->single = fresh.single;
     }
     else if (!strcmp(name, "grid_blocks_per_cu") && value >= 1 && value <= 64)
         ctx->grid_blocks_per_cu = value;
     else if (!strcmp(name, "ilp16") && (value == 0 || value == 1 || value == 2))
         ctx->ilp16 = value;
-    else if (!strcmp(name, "ilp1") && (value == 1 || value == 2 || value == 4))
+    else if (!strcmp(name, "ilp1") && (value == 1 || value == 2 || value == 4)) {
         ctx->ilp1 = value;
+        ctx->single.set = false;        // an explicit setting replaces a calibrated shape
+    }
     else if (!strcmp(name, "nontemporal") && (value == 0 || value == 1))
         ctx->nontemporal = value;
     else if (!strcmp(name, "xcd_slabs") && (value == 0 || value == 1))
@@ -1480,6 +1487,104 @@ int gcn10_gpu_stream_copy(gcn10_gpu_ctx *ctx, const void *src, void *dst, size_t
         hipLaunchKernelGGL(stream_copy_kernel, dim3(grid), dim3(kThreads), 0, s, in, out, nvec, ntrips);
     }
     HIP_TRY(hipGetLastError());
+    return GCN10_OK;
+}
+
+int gcn10_gpu_tune_single_raster(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, int rows, const int32_t *cj,
+                                 unsigned cond_mask, unsigned table_mask, uint8_t *arena, size_t arena_bytes,
+                                 size_t step, uint8_t **best_out, float *best_ms, char *report, size_t report_cap,
+                                 gcn10_stream_t stream)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (!best_out || !arena || !esa || !cj)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_tune_single_raster: null pointer");
+    if (popcount(cond_mask & 3u) != 1 || popcount(table_mask & 0x1ffu) != 1 || (cond_mask & ~3u) || (table_mask >> 9))
+        return fail(GCN10_E_INVAL, "gcn10_gpu_tune_single_raster: exactly one condition and one table");
+    if (W <= 0 || rows <= 0 || (uint64_t)W * (uint64_t)rows > 0x7fffffffull)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_tune_single_raster: bad shape %d x %d", W, rows);
+    const size_t npix = (size_t)W * (size_t)rows;
+    if (step == 0 || (step & 255u) || !aligned16(arena) || arena_bytes < npix)
+        return fail(GCN10_E_INVAL, "gcn10_gpu_tune_single_raster: arena of %zu bytes / step %zu cannot hold a raster of %zu",
+                    arena_bytes, step, npix);
+    const int r = (cond_mask & 2u ? 9 : 0) + __builtin_ctz(table_mask);
+    struct Shape { int xcd, bpc, ilp, pf; };
+    static const Shape shapes[] = { {1, 8, 2, 1}, {1, 16, 2, 1}, {0, 16, 2, 1}, {0, 16, 4, 0}, {1, 8, 4, 0}, {0, 8, 4, 0},
+                                    {1, 16, 1, 0}, {0, 16, 2, 0} };
+    const gcn10_gpu_ctx::SingleShape saved = ctx->single;
+    hipStream_t s = as_stream(ctx, stream);
+    constexpr int kRuns = 3;
+    hipEvent_t e0[kRuns], e1[kRuns];
+    for (int i = 0; i < kRuns; i++) {
+        e0[i] = e1[i] = nullptr;
+        if (hipEventCreate(&e0[i]) != hipSuccess || hipEventCreate(&e1[i]) != hipSuccess)
+            return fail(GCN10_E_HIP, "gcn10_gpu_tune_single_raster: event creation failed");
+    }
+    float best = 1e30f, worst = 0.f;
+    size_t best_pos = 0;
+    Shape best_shape = shapes[0];
+    int n_pos = 0;
+    rc = GCN10_OK;
+    for (size_t pos = 0; pos + npix <= arena_bytes && rc == GCN10_OK; pos += step, n_pos++) {
+        uint8_t *out[GCN10_N_RASTERS] = { nullptr };
+        out[r] = arena + pos;
+        for (const Shape &sh : shapes) {
+            ctx->single.set = true;
+            ctx->single.xcd_slabs = sh.xcd;
+            ctx->single.grid_blocks_per_cu = sh.bpc;
+            ctx->single.ilp = sh.ilp;
+            ctx->single.prefetch = sh.pf;
+            rc = gcn10_gpu_cn_strip(ctx, esa, W, rows, cj, cond_mask, table_mask, out, stream);     // untimed
+            for (int i = 0; i < kRuns && rc == GCN10_OK; i++) {
+                ctx->time_start = e0[i];
+                ctx->time_stop = e1[i];
+                rc = gcn10_gpu_cn_strip(ctx, esa, W, rows, cj, cond_mask, table_mask, out, stream);
+            }
+            if (rc != GCN10_OK)
+                break;
+            if (hipStreamSynchronize(s) != hipSuccess) {
+                rc = fail(GCN10_E_HIP, "gcn10_gpu_tune_single_raster: stream synchronisation failed");
+                break;
+            }
+            float ms[kRuns];
+            for (int i = 0; i < kRuns; i++)
+                if (hipEventElapsedTime(&ms[i], e0[i], e1[i]) != hipSuccess)
+                    ms[i] = 1e30f;
+            // median of three
+            const float lo = ms[0] < ms[1] ? ms[0] : ms[1], hi = ms[0] < ms[1] ? ms[1] : ms[0];
+            const float med = ms[2] < lo ? lo : (ms[2] > hi ? hi : ms[2]);
+            if (med < best) {
+                best = med;
+                best_pos = pos;
+                best_shape = sh;
+            }
+            if (med > worst && med < 1e29f)
+                worst = med;
+        }
+    }
+    for (int i = 0; i < kRuns; i++) {
+        (void)hipEventDestroy(e0[i]);
+        (void)hipEventDestroy(e1[i]);
+    }
+    ctx->time_start = ctx->time_stop = nullptr;
+    ctx->single = saved;
+    if (rc != GCN10_OK)
+        return rc;
+    ctx->single.set = true;
+    ctx->single.xcd_slabs = best_shape.xcd;
+    ctx->single.grid_blocks_per_cu = best_shape.bpc;
+    ctx->single.ilp = best_shape.ilp;
+    ctx->single.prefetch = best_shape.pf;
+    *best_out = arena + best_pos;
+    if (best_ms)
+        *best_ms = best;
+    if (report && report_cap)
+        snprintf(report, report_cap,
+                 "{\"positions\": %d, \"step_bytes\": %zu, \"shapes\": %zu, \"best_ms\": %.4f, \"worst_ms\": %.4f, "
+                 "\"best_offset_bytes\": %zu, \"xcd_slabs\": %d, \"grid_blocks_per_cu\": %d, \"ilp1\": %d, \"prefetch\": %d}",
+                 n_pos, step, sizeof shapes / sizeof shapes[0], best, worst, best_pos, best_shape.xcd, best_shape.bpc,
+                 best_shape.ilp, best_shape.pf);
     return GCN10_OK;
 }
 

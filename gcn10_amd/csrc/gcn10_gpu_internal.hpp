@@ -55,6 +55,12 @@ struct gcn10_gpu_ctx {
     int xcd_slabs = 1;
     int prefetch = 1;       // software pipeline: loads of the next trip issued before the current one is
                             // consumed (two register sets; -1 = default = on)
+    // launch shape of the single-table strip kernel as gcn10_gpu_tune_single_raster left it (the knobs
+    // above keep steering the all-tables kernel)
+    struct SingleShape {
+        bool set = false;
+        int xcd_slabs = 1, grid_blocks_per_cu = 8, ilp = 2, prefetch = 1;
+    } single;
     hipEvent_t time_start = nullptr, time_stop = nullptr;  // one-shot: bracket the next strip kernel
     uint8_t *d_class_of = nullptr;  // [36][256] pixel class of (soil code, landcover), then [18][256] values
     int n_classes = 0;              // 0: not available (set_tables not called, or > 256 classes)

@@ -9,6 +9,7 @@
 #include "gcn10_host.h"
 
 #include <ctype.h>
+#include <stdbool.h>
 #include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -38,6 +39,64 @@ static int set_str(char **slot, const char *val)
     return 0;
 }
 
+int gcn10_parse_lookups(const char *text, unsigned *mask)
+{
+    char buf[256];
+    unsigned m = 0;
+
+    if (!text || strlen(text) >= sizeof buf)
+        return -1;
+    strcpy(buf, text);
+    for (char *tok = strtok(buf, ", \t"); tok; tok = strtok(NULL, ", \t")) {
+        bool found = false;
+
+        if (!strcmp(tok, "all")) {
+            m |= 0x1ffu;
+            continue;
+        }
+        for (int hi = 0; hi < 3 && !found; hi++)
+            for (int ai = 0; ai < 3 && !found; ai++) {
+                char name[16];
+
+                snprintf(name, sizeof name, "%s_%s", gcn10_hcs[hi], gcn10_arcs[ai]);
+                if (!strcmp(tok, name)) {
+                    m |= 1u << (hi * 3 + ai);
+                    found = true;
+                }
+            }
+        if (!found)
+            return -1;
+    }
+    if (!m)
+        return -1;
+    *mask = m;
+    return 0;
+}
+
+int gcn10_parse_conditions(const char *text, unsigned *mask)
+{
+    char buf[64];
+    unsigned m = 0;
+
+    if (!text || strlen(text) >= sizeof buf)
+        return -1;
+    strcpy(buf, text);
+    for (char *tok = strtok(buf, ", \t"); tok; tok = strtok(NULL, ", \t")) {
+        if (!strcmp(tok, "both") || !strcmp(tok, "all"))
+            m |= 3u;
+        else if (!strcmp(tok, gcn10_conds[0]))
+            m |= 1u;
+        else if (!strcmp(tok, gcn10_conds[1]))
+            m |= 2u;
+        else
+            return -1;
+    }
+    if (!m)
+        return -1;
+    *mask = m;
+    return 0;
+}
+
 int gcn10_config_parse(const char *path, gcn10_config *cfg, char *err, size_t errcap)
 {
     char line[512];                                     /* src/config.c:47 */
@@ -46,6 +105,8 @@ int gcn10_config_parse(const char *path, gcn10_config *cfg, char *err, size_t er
     memset(cfg, 0, sizeof *cfg);
     cfg->gpu_deflate = 2;
     cfg->gpu_inflate = 1;
+    cfg->table_mask = 0x1ffu;
+    cfg->cond_mask = 3u;
     f = fopen(path, "r");
     if (!f) {
         snprintf(err, errcap, "cannot open config '%s'", path);     /* src/config.c:52 */
@@ -91,6 +152,17 @@ int gcn10_config_parse(const char *path, gcn10_config *cfg, char *err, size_t er
             cfg->deflate_level = atoi(val);
         else if (!strcmp(key, "gpu_deflate"))
             cfg->gpu_deflate = atoi(val) < 0 ? 0 : (atoi(val) > 2 ? 2 : atoi(val));
+        else if (!strcmp(key, "lookups") || !strcmp(key, "conditions")) {
+            const bool lk = key[0] == 'l';
+
+            if ((lk ? gcn10_parse_lookups(val, &cfg->table_mask) : gcn10_parse_conditions(val, &cfg->cond_mask)) != 0) {
+                fclose(f);
+                snprintf(err, errcap, "bad value for %s: '%s' (%s)", key, val,
+                         lk ? "names like g_ii, p_i,f_iii or all" : "drained, undrained or both");
+                gcn10_config_free(cfg);
+                return -3;
+            }
+        }
         if (rc != 0) {
             fclose(f);
             snprintf(err, errcap, "malloc failed for %s", key);     /* src/config.c:71 */

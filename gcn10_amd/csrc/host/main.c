@@ -3,7 +3,8 @@
  * Same flags as the reference program (/root/reference/src/main.c:85-98):
  *   gcn10 -c|--config <file> [-l|--blocks <file>] [-o|--overwrite] [-h|--help] [-v|--version]
  * plus -b as a synonym of -l (the reference's usage text advertises -b,
- * src/main.c:28, while its parser only takes -l, src/main.c:90) and --gpus N.
+ * src/main.c:28, while its parser only takes -l, src/main.c:90), --gpus N, and --lookups /
+ * --conditions to produce a subset of the 18 rasters (BASELINE config 3: "single lookup").
  * No mpirun: one process drives every GPU of the node.
  */
 #include "gcn10_host.h"
@@ -18,6 +19,7 @@ static void usage(FILE *fp)
             "gcn10 - high-resolution curve number generator, MI355X edition\n"
             "usage:\n"
             "  gcn10 --config <config.txt> [--blocks <blocks.txt>] [--overwrite] [--gpus <n>]\n"
+            "        [--lookups <names>] [--conditions drained|undrained|both]\n"
             "  gcn10 --help | -h | --version | -v\n"
             "\n"
             "options:\n"
@@ -25,6 +27,8 @@ static void usage(FILE *fp)
             "  --blocks, -l, -b <file>\toptional list of block ids to process\n"
             "  --overwrite, -o\toverwrite existing outputs if present (optional)\n"
             "  --gpus <n>\t\tnumber of GPUs to use (default: all visible)\n"
+            "  --lookups <names>\tonly these lookups, e.g. g_ii or p_i,f_iii (default: all nine)\n"
+            "  --conditions <c>\tdrained, undrained or both (default: both)\n"
             "  --help, -h\t\tshow this help and exit\n"
             "  --version, -v\tprint version and exit\n"
             "\n"
@@ -59,6 +63,10 @@ int main(int argc, char **argv)
             opt.overwrite = true;
         else if (!strcmp(argv[i], "--gpus") && i + 1 < argc)
             opt.gpus = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--lookups") && i + 1 < argc)
+            opt.lookups = argv[++i];
+        else if (!strcmp(argv[i], "--conditions") && i + 1 < argc)
+            opt.conditions = argv[++i];
     }
     return gcn10_run(&opt);
 }

@@ -215,14 +215,14 @@ static int drain_strip_inner(struct worker *w, struct strip_buf *b, gcn10_tiff_w
                 g->event_record(w->ctx, b->ev_d2h, w->s_d2h) != 0)
                 goto gpu_error;
         }
-        for (int k = 0; k < GCN10_N_RASTERS; k++) {
+        for (int q = 0; q < r->n_sel; q++) {       /* stream q of the table = the q-th selected raster */
             struct put_job *j = malloc(sizeof *j);
 
             if (!j) {
                 wlog(w, "ERROR", true, "malloc failed for tile job");
                 return -1;
             }
-            *j = (struct put_job){ w, b, tifs[k], k, b->y0 / TILE, across, down };
+            *j = (struct put_job){ w, b, tifs[r->sel[q]], q, b->y0 / TILE, across, down };
             pthread_mutex_lock(&b->mu);
             b->pending++;
             pthread_mutex_unlock(&b->mu);
@@ -241,7 +241,8 @@ gpu_error:
     if (r->null_sink)
         return 0;
     for (int ty = b->y0 / TILE; ty * TILE < b->y0 + b->rows; ty++) {
-        for (int k = 0; k < GCN10_N_RASTERS; k++) {
+        for (int q = 0; q < r->n_sel; q++) {
+            const int k = r->sel[q];
             struct tile_job *j = malloc(sizeof *j);
 
             if (!j) {
@@ -318,7 +319,9 @@ static int ensure_strip_buffers(struct worker *w, int W)
         struct strip_buf *b = &w->buf[i];
 
         /* (landcover staging h_esa / d_esa: only when a block goes through the host reader) */
-        for (int k = 0; k < GCN10_N_RASTERS; k++) {
+        for (int q = 0; q < w->run->n_sel; q++) {
+            const int k = w->run->sel[q];
+
             if (!w->run->gpu_deflate)
                 GPU_TRY(w, g->host_alloc(w->ctx, px, (void **)&b->h_out[k]));
             if (!w->fused)
@@ -342,8 +345,13 @@ static int ensure_strip_buffers(struct worker *w, int W)
             GPU_TRY(w, g->malloc(w->ctx, 8, (void **)&b->d_cursor));
             GPU_TRY(w, g->host_alloc(w->ctx, 8, (void **)&b->h_cursor));
             if (!w->fused) {
+                /* the per-raster encoder takes the selected strips, packed in raster order */
+                uint8_t *packed[GCN10_N_RASTERS] = { 0 };
+
+                for (int q = 0; q < w->run->n_sel; q++)
+                    packed[q] = b->d_out[w->run->sel[q]];
                 GPU_TRY(w, g->malloc(w->ctx, GCN10_N_RASTERS * sizeof(void *), (void **)&b->d_ptrs));
-                GPU_TRY(w, g->memcpy_h2d(w->ctx, (void *)b->d_ptrs, b->d_out, GCN10_N_RASTERS * sizeof(void *),
+                GPU_TRY(w, g->memcpy_h2d(w->ctx, (void *)b->d_ptrs, packed, GCN10_N_RASTERS * sizeof(void *),
                                          w->s_kernel));
                 GPU_TRY(w, g->stream_sync(w->ctx, w->s_kernel));
             }
@@ -477,6 +485,8 @@ static int process_block(struct worker *w, int block_id)
     for (int c = 0; c < 2 && !r->null_sink; c++) {
         char dir[64];
 
+        if (!(r->cond_mask & (1u << c)))
+            continue;
         snprintf(dir, sizeof dir, "cn_rasters_%s", gcn10_conds[c]);
         if (mkdir(dir, 0755) != 0 && errno != EEXIST) {
             wlog(w, "ERROR", true, "failed to create output directory %s", dir);       /* src/cn.c:250 */
@@ -484,7 +494,8 @@ static int process_block(struct worker *w, int block_id)
             goto out;
         }
     }
-    for (int k = 0; k < GCN10_N_RASTERS && !r->null_sink; k++) {
+    for (int q = 0; q < r->n_sel && !r->null_sink; q++) {
+        const int k = r->sel[q];
         char path[PATH_MAX];
 
         output_path(path, sizeof path, gcn10_conds[k / 9], gcn10_hcs[(k % 9) / 3], gcn10_arcs[k % 3],
@@ -590,20 +601,19 @@ static int process_block(struct worker *w, int block_id)
         /* the strip's kernels on the compute stream */
         if (w->fused) {
             /* landcover + soil -> 18 x compressed tiles in one device pass, no CN strip in HBM */
-            if (g->deflate_fused_strip(w->ctx, d_esa, W, rows, w->d_cj + y0,
-                                       GCN10_COND_DRAINED | GCN10_COND_UNDRAINED, 0x1ffu, b->d_arena,
+            if (g->deflate_fused_strip(w->ctx, d_esa, W, rows, w->d_cj + y0, r->cond_mask, r->table_mask, b->d_arena,
                                        b->arena_cap, b->d_table, b->d_cursor, w->s_kernel) != 0)
                 goto gpu_fail;
         }
         else {
             for (int k = 0; k < GCN10_N_RASTERS; k++)
-                outs[k] = b->d_out[k];
-            if (g->cn_strip(w->ctx, d_esa, W, rows, w->d_cj + y0, GCN10_COND_DRAINED | GCN10_COND_UNDRAINED,
-                            0x1ffu, outs, w->s_kernel) != 0)
+                outs[k] = b->d_out[k];             /* NULL for a raster this run does not produce */
+            if (g->cn_strip(w->ctx, d_esa, W, rows, w->d_cj + y0, r->cond_mask, r->table_mask, outs,
+                            w->s_kernel) != 0)
                 goto gpu_fail;
-            /* encode the 18 strips where they are */
+            /* encode the selected strips where they are */
             if (r->gpu_deflate &&
-                g->deflate_strip(w->ctx, b->d_ptrs, GCN10_N_RASTERS, W, rows, b->d_arena, b->arena_cap,
+                g->deflate_strip(w->ctx, b->d_ptrs, r->n_sel, W, rows, b->d_arena, b->arena_cap,
                                  b->d_table, b->d_cursor, w->s_kernel) != 0)
                 goto gpu_fail;
         }
@@ -617,13 +627,13 @@ static int process_block(struct worker *w, int block_id)
 
             if (g->memcpy_d2h(w->ctx, b->h_cursor, b->d_cursor, 8, w->s_d2h) != 0 ||
                 g->memcpy_d2h(w->ctx, b->h_table, b->d_table,
-                              (size_t)across * down * GCN10_N_RASTERS * 8, w->s_d2h) != 0 ||
+                              (size_t)across * down * (size_t)r->n_sel * 8, w->s_d2h) != 0 ||
                 g->event_record(w->ctx, b->ev_meta, w->s_d2h) != 0)
                 goto gpu_fail;
         }
         else {
-            for (int k = 0; k < GCN10_N_RASTERS; k++)
-                if (g->memcpy_d2h(w->ctx, b->h_out[k], b->d_out[k], px, w->s_d2h) != 0)
+            for (int q = 0; q < r->n_sel; q++)
+                if (g->memcpy_d2h(w->ctx, b->h_out[r->sel[q]], b->d_out[r->sel[q]], px, w->s_d2h) != 0)
                     goto gpu_fail;
             if (g->event_record(w->ctx, b->ev_d2h, w->s_d2h) != 0)
                 goto gpu_fail;
@@ -694,7 +704,8 @@ out:
     }
     w->t_finish += now_seconds() - t_mark;
     if (ok || (r->null_sink && rc == 0 && !atomic_load(&w->failed))) {
-        for (int k = 0; k < GCN10_N_RASTERS; k++) {
+        for (int q = 0; q < r->n_sel; q++) {
+            const int k = r->sel[q];
             /* src/cn.c:366-373: one completion line and one progress line per raster */
             wlog(w, "INFO", false, "completed condition for %d: %s/%s/%s", block_id, gcn10_conds[k / 9],
                  gcn10_hcs[(k % 9) / 3], gcn10_arcs[k % 3]);
@@ -967,6 +978,19 @@ int gcn10_run(const gcn10_run_options *opt)
         free(r);
         return 1;
     }
+    /* the rasters of this run: all 18 unless "lookups" / "conditions" (config or command line) say less */
+    r->cond_mask = r->cfg.cond_mask;
+    r->table_mask = r->cfg.table_mask;
+    if ((opt->lookups && gcn10_parse_lookups(opt->lookups, &r->table_mask) != 0) ||
+        (opt->conditions && gcn10_parse_conditions(opt->conditions, &r->cond_mask) != 0)) {
+        fprintf(stderr, "[rank 0] bad --lookups / --conditions value; see 'gcn10 -h' for usage.\n");
+        gcn10_config_free(&r->cfg);
+        free(r);
+        return 1;
+    }
+    for (int k = 0; k < GCN10_N_RASTERS; k++)
+        if ((r->cond_mask >> (k / 9)) & 1u && (r->table_mask >> (k % 9)) & 1u)
+            r->sel[r->n_sel++] = k;
     r->null_sink = sink && strcmp(sink, "null") == 0;
     /* 1024 rows: measured best end to end (768..1280 within noise; 1792 fills the GPU's workgroup
      * slots in whole rounds and encodes 16-19 % faster per row, but the coarser hand-over between
@@ -1081,8 +1105,21 @@ int gcn10_run(const gcn10_run_options *opt)
     {
         struct row_error_ctx ctx = { log0 };
 
-        rc = gcn10_load_all_lookup_tables(r->cfg.lookup_table_path, r->tables, &failed_k,
-                                          on_lookup_row_error, &ctx);
+        /* only the lookups this run produces are read (the reference reads one per raster it
+         * writes, src/cn.c:261); a table that is not selected stays "no value" (255, src/cn.c:36-40) */
+        rc = 0;
+        for (int k = 0; k < 9 && rc == 0; k++) {
+            if (!(r->table_mask & (1u << k))) {
+                for (int lc = 0; lc < 256; lc++)
+                    for (int sg = 0; sg < 5; sg++)
+                        r->tables[k][lc][sg] = 255;
+                continue;
+            }
+            rc = gcn10_load_lookup_table(r->cfg.lookup_table_path, gcn10_hcs[k / 3], gcn10_arcs[k % 3], r->tables[k],
+                                         on_lookup_row_error, &ctx);
+            if (rc != 0)
+                failed_k = k;
+        }
         if (rc != 0) {
             const char *hc = gcn10_hcs[failed_k / 3], *arc = gcn10_arcs[failed_k % 3];
 

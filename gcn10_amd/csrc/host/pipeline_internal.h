@@ -104,6 +104,9 @@ struct run {
     bool gpu_inflate;                       /* DEFLATE landcover tiles are decoded on the GPU */
     int n_devices;                          /* visible GPUs; worker i uses device i % n_devices */
     int outer_rank, outer_size;             /* this process among the processes of an mpirun / srun */
+    unsigned cond_mask, table_mask;         /* the rasters this run produces ("conditions" / "lookups") */
+    int n_sel;                              /* how many: popcount(cond_mask) * popcount(table_mask) */
+    int sel[GCN10_N_RASTERS];               /* their raster indices cond*9 + hc*3 + arc, ascending */
 };
 
 double gcn10_now_seconds(void);

@@ -41,7 +41,7 @@ ABI_SYMBOLS = (
     "gcn10_gpu_deflate_arena_bound", "gcn10_gpu_deflate_strip", "gcn10_gpu_time_next_strip",
     "gcn10_gpu_pci_bus_id", "gcn10_gpu_deflate_fused_strip",
     "gcn10_gpu_deflate_fused_available",
-    "gcn10_gpu_inflate_tiles", "gcn10_gpu_stream_copy",
+    "gcn10_gpu_inflate_tiles", "gcn10_gpu_stream_copy", "gcn10_gpu_tune_single_raster",
 )
 
 
@@ -101,6 +101,8 @@ def lib():
             "gcn10_gpu_set_option": (i, [vp, C.c_char_p, i]),
             "gcn10_gpu_time_next_strip": (i, [vp, vp, vp]),
             "gcn10_gpu_stream_copy": (i, [vp, vp, vp, sz, vp]),
+            "gcn10_gpu_tune_single_raster": (i, [vp, vp, i, i, vp, u, u, vp, sz, sz, C.POINTER(vp),
+                                                 C.POINTER(C.c_float), C.c_char_p, sz, vp]),
             "gcn10_gpu_pci_bus_id": (i, [i, C.c_char_p, sz]),
             "gcn10_gpu_deflate_fused_strip": (i, [vp, vp, i, i, vp, u, u, vp, sz, vp, vp, vp]),
             "gcn10_gpu_deflate_fused_available": (i, [vp]),
@@ -269,6 +271,18 @@ class Engine:
 
     def time_next_strip(self, e0, e1):
         self._chk(lib().gcn10_gpu_time_next_strip(self._ctx, e0, e1), "gcn10_gpu_time_next_strip")
+
+    def tune_single_raster(self, esa, W: int, rows: int, cj, cond_mask: int, table_mask: int, arena, arena_bytes: int,
+                           step: int = 16 << 20, stream=None):
+        """gcn10_gpu_tune_single_raster: (best raster pointer inside the arena, best ms, report dict)."""
+        import json as _json
+        best = C.c_void_p()
+        ms = C.c_float()
+        rep = C.create_string_buffer(512)
+        self._chk(lib().gcn10_gpu_tune_single_raster(self._ctx, esa, W, rows, cj, cond_mask, table_mask, arena,
+                                                     int(arena_bytes), int(step), C.byref(best), C.byref(ms), rep, 512,
+                                                     stream), "gcn10_gpu_tune_single_raster")
+        return best.value, float(ms.value), _json.loads(rep.value.decode() or "{}")
 
     def stream_copy(self, src, dst, nbytes: int, stream=None):
         """Plain 1R:1W copy with the strip kernel's launch shape (the same-run streaming ceiling)."""

@@ -253,6 +253,26 @@ int gcn10_gpu_time_next_strip(gcn10_gpu_ctx *ctx, gcn10_event_t start, gcn10_eve
 int gcn10_gpu_stream_copy(gcn10_gpu_ctx *ctx, const void *src, void *dst, size_t bytes,
                           gcn10_stream_t stream);
 
+/* Placement and launch-shape calibration for one-raster strips (BASELINE config 2 / config 3).
+ * A strip with one raster is a 1 byte read : 1 byte written stream, and on MI355X the rate of such a
+ * stream depends on where the written buffer lies relative to the read one -- periodically in the
+ * distance, with a 128 MiB period for a grid-stride sweep, by up to 20 % (DESIGN.md section 5,
+ * profiles/r02/offset_lab_*.jsonl) -- and the best workgroup -> address mapping depends on it too.
+ * The call times the single-raster kernel of (cond_mask, table_mask: one bit each) on this very
+ * landcover strip for every position arena + i * step (step a multiple of 256; while a raster of
+ * W * rows bytes still fits in arena_bytes) and a fixed set of launch shapes, keeps the fastest
+ * shape for later single-raster launches of this context (the all-tables kernel is not affected;
+ * gcn10_gpu_set_option "ilp1" or "defaults" drops it) and returns the fastest position.
+ * The arena is caller-owned device memory; its contents are overwritten.  `report` (optional)
+ * receives a one-line JSON summary.  Results of later launches do not depend on any of this.
+ * Synchronises `stream`.  No counterpart in the reference (its buffers are malloc'ed per raster,
+ * src/cn.c:264,278). */
+int gcn10_gpu_tune_single_raster(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, int rows,
+                                 const int32_t *cj, unsigned cond_mask, unsigned table_mask,
+                                 uint8_t *arena, size_t arena_bytes, size_t step,
+                                 uint8_t **best_out, float *best_ms, char *report, size_t report_cap,
+                                 gcn10_stream_t stream);
+
 /* Name of the variant of the strip kernel the last cn_strip call launched
  * (for profiles and bench records). */
 const char *gcn10_gpu_last_kernel_name(gcn10_gpu_ctx *ctx);

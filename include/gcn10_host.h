@@ -101,9 +101,19 @@ typedef struct gcn10_config {
                                0 = raw strips are copied back, host zlib threads encode */
     int gpu_inflate;        /* "gpu_inflate": 1 (default) DEFLATE-compressed landcover tiles cross PCIe
                                compressed and are decoded on the GPU; 0 = on the host i/o pool */
+    unsigned table_mask;    /* "lookups": which of the nine lookups to produce, e.g. "g_ii" or "p_i,f_iii"
+                               ("all" / absent = all nine); bit k = hc*3 + arc in the reference's loop
+                               order p,f,g x i,ii,iii (src/cn.c:146-147) */
+    unsigned cond_mask;     /* "conditions": "drained", "undrained" or "both" (absent = both);
+                               bit 0 = drained, bit 1 = undrained (src/cn.c:145) */
 } gcn10_config;
 
-/* Returns 0; -1 cannot open (message in err); -2 a required key is missing
+/* "g_ii", "p_i,f_iii", "all" -> table mask; "drained" | "undrained" | "both" | "all" -> condition mask.
+ * Return 0 and set *mask, or -1 for a name that is not a lookup / condition. */
+int gcn10_parse_lookups(const char *text, unsigned *mask);
+int gcn10_parse_conditions(const char *text, unsigned *mask);
+
+/* Returns 0; -1 cannot open (message in err); -3 a bad "lookups" / "conditions" value; -2 a required key is missing
  * (the reference aborts in both cases, src/config.c:50-54, 107-113). */
 int gcn10_config_parse(const char *path, gcn10_config *cfg, char *err, size_t errcap);
 void gcn10_config_free(gcn10_config *cfg);
@@ -207,6 +217,8 @@ typedef struct gcn10_run_options {
     const char *blocks_file;    /* -l / -b / --blocks, NULL = every shapefile ID */
     bool overwrite;             /* -o / --overwrite                              */
     int gpus;                   /* --gpus N, 0 = config key "gpus" or all visible */
+    const char *lookups;        /* --lookups g_ii[,..]: overrides the config key "lookups"       */
+    const char *conditions;     /* --conditions drained|undrained|both: overrides "conditions" */
 } gcn10_run_options;
 
 /* Runs the whole job: config, logs, block ids, lookup tables, one worker thread

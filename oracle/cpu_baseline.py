@@ -154,7 +154,10 @@ def main():
         best = run_leg("fused single pass, -O3 -march=native, P=%d" % nphys, nphys, cpus, W, rows_best, a.cond_mask,
                        a.table_mask, a.lookups, fused=True)
         best["gpx_per_s"] = round(best["gpx_per_s"], 4)
-    headline = max(runs, key=lambda r: r["procs"])       # the all-physical-cores figure
+    # the figure quoted as cpu_baseline.value: the fastest reference-shaped run (all physical cores where
+    # the box lets this process use them; a cgroup CPU quota below that -- cpu_quota_cores -- makes
+    # the quota-sized run the faster one)
+    headline = max(runs, key=lambda r: r["gpx_per_s"])
     for r in runs:
         r["gpx_per_s"] = round(r["gpx_per_s"], 4)
     print(json.dumps({"cores_available": ncores, "physical_cores": nphys, "cpu_quota_cores": cpu_quota_cores(),

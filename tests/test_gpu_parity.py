@@ -177,6 +177,36 @@ def test_launch_shape_knobs_never_change_results(eng9, tables):
         eng9.set_option("defaults", 0)
 
 
+def test_tune_single_raster_picks_a_position_and_changes_no_result(eng9, tables):
+    W, H = 2051, 64
+    esa, gt, coarse, sgt = make_block(99, H, W, 4, 90, nasty=True)
+    want = oc.process_block_mem(esa, gt, coarse, sgt, tables, cond_mask=2, table_mask=1 << 3)
+    hsy, hsx = coarse.shape
+    ci, cj = host.build_index_maps(gt, sgt, W, H, hsx, hsy)
+    e = eng9
+    bufs = [e.upload(esa), e.upload(coarse), e.upload(ci), e.upload(cj)]
+    npix = W * H
+    arena = e.alloc(npix + 5 * 4096)
+    try:
+        e.prepare_tile(bufs[1].ptr, hsx, hsy, bufs[2].ptr, W)
+        best, ms, rep = e.tune_single_raster(bufs[0].ptr, W, H, bufs[3].ptr, 2, 1 << 3, arena.ptr, npix + 5 * 4096, 4096)
+        assert arena.ptr <= best <= arena.ptr + 5 * 4096 and (best - arena.ptr) % 4096 == 0
+        assert rep["positions"] == 6 and rep["best_ms"] == pytest.approx(ms, abs=1e-3) and 0 < ms <= rep["worst_ms"]
+        ptrs = [None] * 18
+        ptrs[9 + 3] = best
+        e.cn_strip(bufs[0].ptr, W, H, bufs[3].ptr, 2, 1 << 3, ptrs)
+        e.sync()
+        assert np.array_equal(e.download(best, (H, W)), want[9 + 3])
+        with pytest.raises(gpu.Gcn10GpuError):
+            e.tune_single_raster(bufs[0].ptr, W, H, bufs[3].ptr, 3, 1 << 3, arena.ptr, npix, 4096)   # two conditions
+        with pytest.raises(gpu.Gcn10GpuError):
+            e.tune_single_raster(bufs[0].ptr, W, H, bufs[3].ptr, 1, 1 << 3, arena.ptr, npix - 1, 4096)   # arena too small
+    finally:
+        e.set_option("defaults", 0)
+        for b in bufs + [arena]:
+            b.close()
+
+
 def test_stream_copy_is_a_copy(engine):
     n = 16 * 100003
     src = np.random.default_rng(5).integers(0, 256, size=n, dtype=np.uint8)
