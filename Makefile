@@ -49,7 +49,13 @@ asan-host:
 	    ASAN_OPTIONS=detect_leaks=0 GCN10_HOST_LIB=/tmp/libgcn10_host_asan.so \
 	    python -m pytest tests/test_host.py tests/test_host_io.py tests/test_host_fuzz.py -q
 
+# the threaded host program (block workers, strip hand-over, sink pool) under ThreadSanitizer, against the
+# asynchronous host stub of the GPU library (tests/stub_gpu: test infrastructure, never a fallback);
+# 3 workers x 8 blocks through gcn10_run in three sink modes, rasters compared with the oracle
+tsan-host: oracle host
+	python3 tests/tsan_host.py profiles/r02/tsan_host.log
+
 clean:
 	rm -f $(PKG)/*.so bin/gcn10
 	$(MAKE) -C oracle clean
-.PHONY: all gpu host cli oracle clean asan-host
+.PHONY: all gpu host cli oracle clean asan-host tsan-host

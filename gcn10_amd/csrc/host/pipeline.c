@@ -780,11 +780,14 @@ static void bind_to_gpu_numa_node(struct worker *w, int device)
     cpu_set_t set;
     char *p;
 
-    if (getenv("GCN10_NO_NUMA_BIND") || w->run->gpu->pci_bus_id(device, bus, sizeof bus) != 0)
+    w->device = device;
+    w->numa_node = -1;
+    if (w->run->gpu->pci_bus_id(device, bus, sizeof bus) != 0)
         return;
     for (char *c = bus; *c; c++)
         if (*c >= 'A' && *c <= 'F')
             *c = (char)(*c - 'A' + 'a');        /* sysfs names are lower case */
+    snprintf(w->pci_bus, sizeof w->pci_bus, "%s", bus);
     snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
     f = fopen(path, "r");
     if (!f)
@@ -792,7 +795,8 @@ static void bind_to_gpu_numa_node(struct worker *w, int device)
     if (fscanf(f, "%d", &node) != 1)
         node = -1;
     fclose(f);
-    if (node < 0)
+    w->numa_node = node;
+    if (node < 0 || getenv("GCN10_NO_NUMA_BIND"))
         return;
     snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
     f = fopen(path, "r");
@@ -1220,6 +1224,37 @@ int gcn10_run(const gcn10_run_options *opt)
                  r->gpu_deflate ? (r->fused ? ", fused gpu deflate" : ", gpu deflate") : ", host zlib",
                  r->gpu_inflate ? ", gpu inflate of deflate landcover" : "", busy, rd, gw, sw, so, cr, fi, dv);
         gcn10_log_message(log0, "INFO", msg, false);
+        /* one line per GPU: when a node's GPUs are not equally busy, these tell a slow device or PCIe
+         * root complex (waiting for gpu) from a slow NUMA node or file system (reading, waiting for sink) */
+        for (int d = 0; d < r->n_devices; d++) {
+            int nw = 0, nb = 0;
+            double b_ = 0, rd_ = 0, gw_ = 0, sw_ = 0, so_ = 0, fi_ = 0;
+            const struct worker *first = NULL;
+
+            for (int i = 0; i < r->n_workers; i++) {
+                const struct worker *w = &r->workers[i];
+
+                if (w->index % r->n_devices != d)
+                    continue;
+                if (!first)
+                    first = w;
+                nw++;
+                nb += w->blocks_done;
+                b_ += w->busy_seconds;
+                rd_ += w->t_read;
+                gw_ += w->t_gpu_wait;
+                sw_ += w->t_sink_wait;
+                so_ += w->t_soil;
+                fi_ += w->t_finish;
+            }
+            if (!first)
+                continue;
+            snprintf(msg, sizeof msg, "timing gpu %d (pci %s, numa node %d): %d worker(s), %d blocks, worker seconds: "
+                     "in blocks %.3f, reading landcover %.3f, waiting for gpu %.3f, waiting for sink %.3f, "
+                     "soil window %.3f, finishing outputs %.3f",
+                     d, first->pci_bus[0] ? first->pci_bus : "?", first->numa_node, nw, nb, b_, rd_, gw_, sw_, so_, fi_);
+            gcn10_log_message(log0, "INFO", msg, false);
+        }
     }
     exit_code = atomic_load(&r->fatal) ? 1 : 0;
 

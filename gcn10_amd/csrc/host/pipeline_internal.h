@@ -76,6 +76,9 @@ struct worker {
     gcn10_event_t ev_comp, ev_inflate;
     size_t n_inflate;                       /* chunks of the block in flight */
     int blocks_done;
+    int device;                             /* the GPU this worker drives */
+    int numa_node;                          /* ... and the NUMA node it hangs off (-1 = unknown) */
+    char pci_bus[64];
     double busy_seconds;
     double t_first_block;                   /* when this worker started its first block */
     double t_read, t_gpu_wait, t_sink_wait;            /* where the worker thread's time goes */

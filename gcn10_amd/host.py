@@ -85,7 +85,8 @@ class Config(C.Structure):
                 ("log_dir", C.c_char_p), ("gpus", C.c_int), ("workers_per_gpu", C.c_int),
                 ("strip_rows", C.c_int),
                 ("io_threads", C.c_int), ("deflate_level", C.c_int), ("esa_tile_dir", C.c_char_p),
-                ("gpu_deflate", C.c_int), ("gpu_inflate", C.c_int)]
+                ("gpu_deflate", C.c_int), ("gpu_inflate", C.c_int),
+                ("table_mask", C.c_uint), ("cond_mask", C.c_uint)]
 
 
 class Blocks(C.Structure):

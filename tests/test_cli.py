@@ -90,6 +90,8 @@ def test_blocks_equal_oracle_and_reference_conventions(tmp_path, tables, gpu_def
     assert "[ERROR] [rank 0] esa load failed for block 104" in log                # src/cn.c:189
     assert "[ERROR] [rank 0] block 999 not found" in log                          # src/cn.c:173
     assert "processed 5 blocks on 1 ranks" in log                                 # src/main.c:191
+    assert re.search(r"timing gpu 0 \(pci [0-9a-f:.?]+, numa node -?\d+\): 1 worker\(s\), \d+ blocks, worker seconds: "
+                     r"in blocks [\d.]+, reading landcover [\d.]+, waiting for gpu [\d.]+, waiting for sink", log)
     assert len(re.findall(r"completed condition for 101: ", log)) == 18           # src/cn.c:367
     assert len(re.findall(r"progress: completed block 101 / total 5", log)) == 18  # src/log.c:203, 18x
     assert "completed condition for 101: drained/p/i" in log and \
@@ -433,3 +435,74 @@ def test_full_size_block_of_the_real_vrt_shape(tmp_path, tables):
         im = np.array(Image.open(str(p)))
         assert im.shape == (size, size)
         assert np.array_equal(im[y0:y0 + 600], want[r]), p
+
+
+# ---- BASELINE config 3: "single lookup" -- a subset of the 18 rasters ---------------------------
+
+def test_lookups_and_conditions_values_are_checked(tmp_path):
+    _world(tmp_path, extra_cfg="lookups=g_iv\n")
+    out = _run(tmp_path, "-c", "config.txt")
+    assert out.returncode == 1 and "bad value for lookups: 'g_iv'" in out.stderr
+    _world(tmp_path, extra_cfg="conditions=dry\n")
+    out = _run(tmp_path, "-c", "config.txt")
+    assert out.returncode == 1 and "bad value for conditions" in out.stderr
+    _world(tmp_path)
+    out = _run(tmp_path, "-c", "config.txt", "--lookups", "q_i")
+    assert out.returncode == 1 and "bad --lookups / --conditions value" in out.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gpu_deflate", [2, 1, 0], ids=["fused-gpu-deflate", "gpu-deflate", "host-zlib"])
+@pytest.mark.parametrize("how", ["config", "flags"])
+def test_single_lookup_run_equals_oracle_subset(tmp_path, tables, gpu_deflate, how):
+    """lookups=g_ii conditions=drained (config keys or --lookups / --conditions): one raster per block,
+    equal to the oracle's subset pass; nothing else is written, logged or even read (the other eight
+    CSVs need not exist)."""
+    import shutil
+    only = tmp_path / "lookups_only_g_ii"
+    only.mkdir()
+    shutil.copy(os.path.join(LOOKUPS, "default_lookup_g_ii.csv"), only / "default_lookup_g_ii.csv")
+    extra = "gpu_deflate=%d\n" % gpu_deflate
+    if how == "config":
+        extra += "lookups = g_ii\nconditions=drained\n"
+    esa, soil = _world(tmp_path, extra_cfg=extra)
+    cfg = (tmp_path / "config.txt").read_text().replace("lookup_table_path=%s" % LOOKUPS, "lookup_table_path=%s" % only)
+    (tmp_path / "config.txt").write_text(cfg)
+    (tmp_path / "ids.txt").write_text("101 103\n")
+    flags = [] if how == "config" else ["--lookups", "g_ii", "--conditions", "drained"]
+    out = _run(tmp_path, "-c", "config.txt", "-l", "ids.txt", *flags)
+    assert out.returncode == 0, out.stderr[-2000:]
+    log = (tmp_path / "logs" / "rank_0.log").read_text()
+    assert re.findall(r"completed condition for 101: (\S+)", log) == ["drained/g/ii"]
+    assert len(re.findall(r"progress: completed block 103 / total 2", log)) == 1
+    assert not (tmp_path / "cn_rasters_undrained").exists()
+    assert sorted(os.listdir(tmp_path / "cn_rasters_drained")) == ["cn_g_ii_101.tif", "cn_g_ii_103.tif"]
+    k = 2 * 3 + 1                                   # hc = g, arc = ii
+    for bid, *bbox in (BLOCKS[0], BLOCKS[2]):
+        xo, yo, W, H, gt = oc.window(ESA_GT, 3000, 2000, bbox)
+        sxo, syo, hsx, hsy, sgt = oc.window(SOIL_GT, soil.shape[1], soil.shape[0], bbox)
+        want = oc.process_block_mem(esa[yo:yo + H, xo:xo + W], gt, soil[syo:syo + hsy, sxo:sxo + hsx], sgt,
+                                    tables, cond_mask=1, table_mask=1 << k)
+        got = np.array(Image.open(str(tmp_path / "cn_rasters_drained" / ("cn_g_ii_%d.tif" % bid))))
+        assert np.array_equal(got, want[k]), bid
+
+
+@pytest.mark.gpu
+def test_lookup_subset_of_several_tables_and_both_conditions(tmp_path, tables):
+    esa, soil = _world(tmp_path, extra_cfg="lookups=p_i, f_iii,g_ii\n")
+    (tmp_path / "ids.txt").write_text("102\n")
+    out = _run(tmp_path, "-c", "config.txt", "-l", "ids.txt", "--conditions", "undrained,drained")
+    assert out.returncode == 0, out.stderr[-2000:]
+    names = ["cn_%s_102.tif" % n for n in ("f_iii", "g_ii", "p_i")]
+    assert sorted(os.listdir(tmp_path / "cn_rasters_drained")) == names
+    assert sorted(os.listdir(tmp_path / "cn_rasters_undrained")) == names
+    bid, *bbox = BLOCKS[1]
+    xo, yo, W, H, gt = oc.window(ESA_GT, 3000, 2000, bbox)
+    sxo, syo, hsx, hsy, sgt = oc.window(SOIL_GT, soil.shape[1], soil.shape[0], bbox)
+    mask = (1 << 0) | (1 << 5) | (1 << 7)
+    want = oc.process_block_mem(esa[yo:yo + H, xo:xo + W], gt, soil[syo:syo + hsy, sxo:sxo + hsx], sgt, tables,
+                                table_mask=mask)
+    for c, cond in enumerate(CONDS):
+        for k, name in ((0, "p_i"), (5, "f_iii"), (7, "g_ii")):
+            got = np.array(Image.open(str(tmp_path / ("cn_rasters_%s" % cond) / ("cn_%s_102.tif" % name))))
+            assert np.array_equal(got, want[c * 9 + k]), (cond, name)
