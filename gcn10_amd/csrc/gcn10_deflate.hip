@@ -1213,6 +1213,10 @@ int gcn10_gpu_deflate_strip(gcn10_gpu_ctx *ctx, const uint8_t *const *rasters_de
     job.rows = (uint32_t)rows;
     job.across = ((uint32_t)W + kTile - 1) / kTile;
     job.down = ((uint32_t)rows + kTile - 1) / kTile;
+    // stream offsets are 32-bit table entries with 0xfffffffe / 0xffffffff reserved
+    if (arena_cap >= 0xfffffffeull)
+        return fail(GCN10_E_INVAL, "tile encoder: an arena of %zu bytes does not fit 32-bit stream offsets "
+                                   "(use fewer rows per strip)", arena_cap);
     job.arena_cap = arena_cap;
     const uint64_t nblocks = (uint64_t)job.across * job.down * (uint64_t)n_rasters;
     if (nblocks > 0x7fffffffull)

@@ -725,6 +725,10 @@ int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W,
     job.t.rows = (uint32_t)rows;
     job.t.across = ((uint32_t)W + kTile - 1) / kTile;
     job.t.down = ((uint32_t)rows + kTile - 1) / kTile;
+    // stream offsets are 32-bit table entries with 0xfffffffe / 0xffffffff reserved
+    if (arena_cap >= 0xfffffffeull)
+        return fail(GCN10_E_INVAL, "tile encoder: an arena of %zu bytes does not fit 32-bit stream offsets "
+                                   "(use fewer rows per strip)", arena_cap);
     job.t.arena_cap = arena_cap;
     const uint32_t positions = job.t.across * job.t.down;
     const uint64_t nblocks = (uint64_t)positions * job.n_sel;

@@ -121,7 +121,8 @@ static void put_tiles_job(void *arg)
             const size_t i = (size_t)ty * j->across + tx;
             const uint32_t off = tab[i * 2], size = tab[i * 2 + 1];
 
-            if (off == 0xffffffffu || size == 0 || (size_t)off + size > j->b->arena_cap) {
+            /* the host copy holds exactly the `used` bytes the encoder produced, not arena_cap */
+            if (off == 0xffffffffu || size == 0 || (size_t)off + size > j->b->h_tiles_used) {
                 ok = false;
                 break;
             }
@@ -210,6 +211,7 @@ static int drain_strip_inner(struct worker *w, struct strip_buf *b, gcn10_tiff_w
                 dst = b->h_spill;
             }
             b->h_tiles = dst;
+            b->h_tiles_used = used;
             /* the sink jobs wait for this copy themselves: the worker goes on to the next strip */
             if (g->memcpy_d2h(w->ctx, dst, b->d_arena, used, w->s_d2h) != 0 ||
                 g->event_record(w->ctx, b->ev_d2h, w->s_d2h) != 0)
@@ -1000,6 +1002,8 @@ int gcn10_run(const gcn10_run_options *opt)
      * slots in whole rounds and encodes 16-19 % faster per row, but the coarser hand-over between
      * kernels, copy-back and file writes costs more than that: 0.173 vs 0.156 s per block) */
     r->strip_rows = r->cfg.strip_rows > 0 ? (r->cfg.strip_rows + TILE - 1) / TILE * TILE : DEFAULT_STRIP_ROWS;
+    if (r->strip_rows > MAX_STRIP_ROWS)     /* a strip's compressed-tile arena must stay below 4 GiB (32-bit offsets) */
+        r->strip_rows = MAX_STRIP_ROWS;
     r->deflate_level = r->cfg.deflate_level;
     r->gpu_deflate = r->cfg.gpu_deflate != 0;
     r->fused = r->cfg.gpu_deflate == 2;

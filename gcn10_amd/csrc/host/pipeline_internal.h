@@ -12,7 +12,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-enum { TILE = 256, MAX_NBUF = 4, DEFAULT_NBUF = 3, DEFAULT_STRIP_ROWS = 1024 };
+enum { TILE = 256, MAX_NBUF = 4, DEFAULT_NBUF = 3, DEFAULT_STRIP_ROWS = 1024, MAX_STRIP_ROWS = 4096 };
 
 struct run;
 
@@ -30,6 +30,7 @@ struct strip_buf {
     size_t h_arena_cap;                     /* pinned arena: an eighth of it (>= 32 MB)    */
     uint8_t *h_spill;                       /* pageable stand-in when a strip needs more   */
     const uint8_t *h_tiles;                 /* where this strip's streams are: arena or spill */
+    size_t h_tiles_used;                    /* ... and how many bytes of them the encoder produced */
     uint32_t *d_table, *h_table;            /* [18][tiles][2]; h_table pinned */
     unsigned long long *d_cursor, *h_cursor;
     const uint8_t **d_ptrs;                 /* device array of the 18 d_out pointers */

@@ -1050,6 +1050,7 @@ int gcn10_tiff_finish(gcn10_tiff_writer *w, char *err, size_t errcap)
     size_t nt = (size_t)w->across * (size_t)w->down;
     double scale[3] = { w->gt[1], -w->gt[5], 0.0 };
     double tie[6] = { 0, 0, 0, w->gt[0], w->gt[3], 0 };
+    double xform[16] = { 0 };
     unsigned char s_w[4], s_h[4], s_bps[2], s_comp[2], s_phot[2], s_spp[2], s_plan[2], s_tw[2],
         s_th[2], s_fmt[2];
     struct dirent_w ents[20];
@@ -1095,7 +1096,16 @@ int gcn10_tiff_finish(gcn10_tiff_writer *w, char *err, size_t errcap)
         ENT(33550, T_DOUBLE, 3, scale, sizeof scale);
         ENT(33922, T_DOUBLE, 6, tie, sizeof tie);
     }
-    ENT(34735, T_SHORT, w->georef.n_geokeys, w->georef.geokeys, (size_t)w->georef.n_geokeys * 2);
+    else {
+        /* a rotated or sheared geotransform: ModelTransformationTag, the 4x4 matrix GDAL's
+         * GTiff driver writes for GDALSetGeoTransform in that case (src/raster.c:210) */
+        xform[0] = w->gt[1]; xform[1] = w->gt[2]; xform[3] = w->gt[0];
+        xform[4] = w->gt[4]; xform[5] = w->gt[5]; xform[7] = w->gt[3];
+        xform[15] = 1.0;
+        ENT(34264, T_DOUBLE, 16, xform, sizeof xform);
+    }
+    if (w->georef.n_geokeys > 0 && w->georef.geokeys)
+        ENT(34735, T_SHORT, w->georef.n_geokeys, w->georef.geokeys, (size_t)w->georef.n_geokeys * 2);
     if (w->georef.geodoubles)
         ENT(34736, T_DOUBLE, w->georef.n_geodoubles, w->georef.geodoubles,
             (size_t)w->georef.n_geodoubles * 8);

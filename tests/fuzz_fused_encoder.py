@@ -37,11 +37,16 @@ def landcover(rng, H, W, values):
     return np.ascontiguousarray(img, dtype=np.uint8)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--seconds", type=float, default=120.0)
-    ap.add_argument("--seed", type=int, default=1)
-    a = ap.parse_args()
+class _Args:
+    pass
+
+
+def run(seed=1, seconds=None, cases=None, verbose=True):
+    """Runs until `cases` random blocks are done (or `seconds` have passed).  Returns
+    (cases, streams checked, first difference or None)."""
+    a = _Args()
+    a.seed, a.seconds = seed, (seconds if seconds is not None else 1e9)
+    max_cases = cases if cases is not None else 1 << 60
     rng = np.random.default_rng(a.seed)
     shipped = np.stack([oc.load_lookup_table(os.path.join(LOOKUPS, "default_lookup_%s_%s.csv" % (hc, arc)))[0]
                         for hc in onp.HCS for arc in onp.ARCS])
@@ -49,7 +54,7 @@ def main():
     t_print = time.time()
     cases = tiles_checked = 0
     with gpu.Engine(0) as e:
-        while time.time() < t_end:
+        while time.time() < t_end and cases < max_cases:
             H = int(rng.integers(1, 900))
             W = int(rng.integers(1, 1400))
             if rng.random() < 0.5:
@@ -91,14 +96,29 @@ def main():
                         except zlib.error:
                             ok = False
                         if not ok:
-                            print("DIFFERENCE: case %d seed %d H %d W %d raster %d tile (%d, %d)" % (cases, a.seed, H, W, r, ty, tx))
-                            sys.exit(1)
+                            return cases, tiles_checked, "case %d seed %d H %d W %d raster %d tile (%d, %d)" % (
+                                cases, a.seed, H, W, r, ty, tx)
                         tiles_checked += 1
             cases += 1
-            if time.time() - t_print > 60:
+            if verbose and time.time() - t_print > 60:
                 t_print = time.time()
                 print("... %d cases, %d streams so far, no difference" % (cases, tiles_checked), flush=True)
-    print("cases %d, streams checked %d, differences 0" % (cases, tiles_checked))
+    return cases, tiles_checked, None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=None)
+    ap.add_argument("--cases", type=int, default=None, help="fixed budget of random blocks (instead of a time)")
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    if a.seconds is None and a.cases is None:
+        a.seconds = 120.0
+    n, streams, diff = run(a.seed, a.seconds, a.cases)
+    if diff:
+        print("DIFFERENCE: " + diff)
+        sys.exit(1)
+    print("seed %d: cases %d, streams checked %d, differences 0" % (a.seed, n, streams))
 
 
 if __name__ == "__main__":

@@ -80,19 +80,24 @@ def compress(rng, raw):
     return b"".join(out)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--seconds", type=float, default=60.0)
-    ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256)
-    a = ap.parse_args()
+class _Args:
+    pass
+
+
+def run(seed=1, seconds=None, streams_budget=None, batch=256, verbose=True):
+    """Runs until `streams_budget` random zlib streams are done (or `seconds` have passed).
+    Returns (streams, decoded like zlib, refused, list of differences)."""
+    a = _Args()
+    a.seed, a.batch = seed, batch
+    a.seconds = seconds if seconds is not None else 1e9
+    budget = streams_budget if streams_budget is not None else 1 << 60
     rng = np.random.default_rng(a.seed)
     t_end = time.time() + a.seconds
     t_print = time.time()
     n_ok = n_refused = n_streams = 0
     bad = []
     with gpu.Engine(0) as e:
-        while time.time() < t_end:
+        while time.time() < t_end and n_streams < budget:
             streams, raws, rows = [], [], []
             W = 4096
             for k in range(a.batch):
@@ -141,10 +146,24 @@ def main():
                         n_ok += 1
             if bad:
                 break
-            if time.time() - t_print > 60:
+            if verbose and time.time() - t_print > 60:
                 t_print = time.time()
                 print("... %d streams so far, no difference" % n_streams, flush=True)
-    print("streams %d, decoded like zlib %d, refused %d, differences %d %s" % (n_streams, n_ok, n_refused, len(bad), bad[:5]))
+    return n_streams, n_ok, n_refused, bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=None)
+    ap.add_argument("--streams", type=int, default=None, help="fixed budget of random streams (instead of a time)")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256)
+    a = ap.parse_args()
+    if a.seconds is None and a.streams is None:
+        a.seconds = 60.0
+    n_streams, n_ok, n_refused, bad = run(a.seed, a.seconds, a.streams, a.batch)
+    print("seed %d: streams %d, decoded like zlib %d, refused %d, differences %d %s" % (a.seed, n_streams, n_ok, n_refused,
+                                                                                       len(bad), bad[:5]))
     sys.exit(1 if bad else 0)
 
 
