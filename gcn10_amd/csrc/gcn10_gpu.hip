@@ -1510,8 +1510,10 @@ int gcn10_gpu_tune_single_raster(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, 
                     arena_bytes, step, npix);
     const int r = (cond_mask & 2u ? 9 : 0) + __builtin_ctz(table_mask);
     struct Shape { int xcd, bpc, ilp, pf; };
-    static const Shape shapes[] = { {1, 8, 2, 1}, {1, 16, 2, 1}, {0, 16, 2, 1}, {0, 16, 4, 0}, {1, 8, 4, 0}, {0, 8, 4, 0},
-                                    {1, 16, 1, 0}, {0, 16, 2, 0} };
+    // XCD slabs only: a grid-stride sweep is 1-2 % faster at its best positions, but every XCD then pulls
+    // every soil row through the fabric (FETCH_SIZE 1.18x the algorithmic bytes against 1.03x, profiles/r02)
+    static const Shape shapes[] = { {1, 8, 2, 1}, {1, 16, 2, 1}, {1, 8, 4, 0}, {1, 16, 4, 0}, {1, 16, 1, 0}, {1, 8, 2, 0},
+                                    {1, 16, 2, 0}, {1, 8, 1, 1} };
     const gcn10_gpu_ctx::SingleShape saved = ctx->single;
     hipStream_t s = as_stream(ctx, stream);
     constexpr int kRuns = 3;

@@ -60,6 +60,14 @@ static void comp_job_run(void *arg)
     free(j);
 }
 
+/* longest compressed stream first */
+static int by_size_desc(const void *a, const void *b)
+{
+    const struct gcn10_chunk_ref *x = a, *y = b;
+
+    return x->nbytes < y->nbytes ? 1 : (x->nbytes > y->nbytes ? -1 : 0);
+}
+
 int gcn10_inflate_block(struct worker *w, int xoff, int yoff, int W, int H, int block_id)
 {
     struct run *r = w->run;
@@ -80,6 +88,11 @@ int gcn10_inflate_block(struct worker *w, int xoff, int yoff, int W, int H, int 
         wlog(w, "ERROR", true, "esa load failed for block %d", block_id);
         return -1;
     }
+    /* one workgroup decodes one stream and the GPU hands workgroups out in index order as slots free
+     * up: with the longest streams first the last, partly filled round of slots (a block's ~1300 tiles
+     * over 1024 slots) decodes the short ones instead of waiting for one long straggler */
+    if (!getenv("GCN10_INFLATE_FILE_ORDER"))      /* (A/B switch for tools/) */
+        qsort(plan.chunks, plan.n, sizeof *plan.chunks, by_size_desc);
     rc = -1;
     if (plan.n > w->jobs_cap) {
         if (w->h_jobs) g->host_free(w->ctx, w->h_jobs);

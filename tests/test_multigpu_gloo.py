@@ -165,3 +165,16 @@ def test_bench_single_rank_with_the_stand_in_engine():
     assert rec["n_gpus"] == 1 and len(rec["per_rank"]) == 1
     assert rec["roofline"]["copy_ceiling"]["kernel"] == "stream_copy_kernel"
     assert rec["also"]["workload"].startswith("config4") and "round1_style_ms_per_launch" in rec["also"]
+
+
+def test_bench_strong_scaling_splits_one_block_into_row_bands():
+    """--scaling strong: SURVEY 8(e) "within a single huge tile, split by row ranges across GPUs"."""
+    out = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "2050", "--no-cpu-baseline",
+                  "--scaling", "strong"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["scaling"] == "strong" and rec["n_gpus"] == 2
+    bands = [r["rows"] for r in rec["per_rank"]]
+    assert bands[0][0] == 0 and bands[0][1] == bands[1][0] and bands[1][1] == 2050 and bands[0][1] % 16 == 0
+    want = 2050 * 2050 * 1 * 3 / (rec["ms_per_step"] * 3e-3) / 1e9          # ONE block over both GPUs
+    assert abs(rec["value"] - want) / want < 1e-3

@@ -274,6 +274,86 @@ __global__ __launch_bounds__(THREADS) void copy_kernel(const u32x4 *in, u32x4 *o
 }
 
 // ---------------------------------------------------------------------------------------------
+// phase-gated copy: every wave issues its loads only while bit TBITS of the chip-wide 100 MHz
+// counter (s_memrealtime) is 0 and its stores only while it is 1, so that the whole chip alternates
+// between reading and writing HBM in slices of 2^TBITS * 10 ns without any communication.  Tests the
+// guess that the ~10 % a 1R:1W stream loses against read-only + write-only time sharing is bus
+// turnaround between the two directions.
+// ---------------------------------------------------------------------------------------------
+template <int TBITS>
+__device__ __forceinline__ void wait_phase(uint32_t want)
+{
+    while (((uint32_t)(__builtin_amdgcn_s_memrealtime() >> TBITS) & 1u) != want)
+        __builtin_amdgcn_s_sleep(1);
+}
+
+template <int UN, int THREADS, int TBITS>
+__global__ __launch_bounds__(THREADS) void copy_phased_kernel(const u32x4 *in, u32x4 *out, size_t nvec)
+{
+    const size_t nchunk = (nvec + THREADS * UN - 1) / (THREADS * UN);
+    const size_t per = (nchunk + 7) / 8, xcd = blockIdx.x & 7;
+    size_t c = xcd * per + (blockIdx.x >> 3);
+    const size_t cend = (xcd + 1) * per < nchunk ? (xcd + 1) * per : nchunk;
+    const size_t cstep = gridDim.x / 8;
+    for (; c < cend; c += cstep) {
+        u32x4 v[UN];
+        size_t idx[UN];
+        wait_phase<TBITS>(0u);
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            idx[u] = (c * UN + u) * THREADS + threadIdx.x;
+            v[u] = __builtin_nontemporal_load(in + (idx[u] < nvec ? idx[u] : 0));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_phase<TBITS>(1u);
+#pragma unroll
+        for (int u = 0; u < UN; u++)
+            if (idx[u] < nvec)
+                __builtin_nontemporal_store(v[u], out + idx[u]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// copy with other cache policies on the store: STM 1 = sc1, 2 = sc0 sc1 (write-through, the line is
+// dropped from L2), 3 = nt sc1, 4 = plain; loads LDM 0 = nt, 1 = plain, 2 = sc1
+// ---------------------------------------------------------------------------------------------
+template <int STM>
+__device__ __forceinline__ void store_policy(u32x4 *p, u32x4 v)
+{
+    if (STM == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+    else if (STM == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
+    else if (STM == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(p), "v"(v) : "memory");
+    else *p = v;
+}
+
+template <int LDM, int STM>
+__global__ __launch_bounds__(256) void copy_policy_kernel(const u32x4 *in, u32x4 *out, size_t nvec)
+{
+    const size_t nchunk = (nvec + 511) / 512;
+    const size_t per = (nchunk + 7) / 8, xcd = blockIdx.x & 7;
+    size_t c = xcd * per + (blockIdx.x >> 3);
+    const size_t cend = (xcd + 1) * per < nchunk ? (xcd + 1) * per : nchunk;
+    const size_t cstep = gridDim.x / 8;
+    for (; c < cend; c += cstep) {
+        u32x4 v[2];
+        size_t idx[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            idx[u] = (c * 2 + u) * 256 + threadIdx.x;
+            const u32x4 *p = in + (idx[u] < nvec ? idx[u] : 0);
+            if (LDM == 0) v[u] = __builtin_nontemporal_load(p);
+            else if (LDM == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[u]) : "v"(p) : "memory");
+            else v[u] = *p;
+        }
+        if (LDM == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            if (idx[u] < nvec)
+                store_policy<STM>(out + idx[u], v[u]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side: every variant is a closure that launches one kernel with the events attached to the
 // dispatch; variants are timed in interleaved rounds (A B C ... A B C ...) so that drift of the box
 // (clocks, temperature) falls on all of them alike.
@@ -345,6 +425,50 @@ static void add_copy(Lab &L, int wg_per_cu)
         void *args[] = {&i_, &o_, &n_};
         CK(hipExtLaunchKernel(reinterpret_cast<const void *>(copy_kernel<UN, THREADS, MAP>), dim3(blocks), dim3(THREADS), args, 0,
                               s, a, b, 0));
+    };
+    L.v.push_back(v);
+}
+
+template <int UN, int THREADS, int TBITS>
+static void add_phased(Lab &L, int wg_per_cu)
+{
+    int blocks = L.cus * wg_per_cu;
+    blocks -= blocks % 8;
+    char name[64];
+    snprintf(name, sizeof name, "copy_phased_un%d_t%d_tbits%d_wg%d", UN, THREADS, TBITS, wg_per_cu);
+    const u32x4 *in = (const u32x4 *)L.pA.esa;
+    u32x4 *out = (u32x4 *)L.outs[0];
+    size_t nvec = L.pA.npix / 16;
+    Variant v;
+    v.name = name; v.blocks = blocks; v.threads = THREADS; v.bytes = 2.0 * L.pA.npix; v.check = nullptr;
+    hipStream_t s = L.s;
+    v.launch = [in, out, nvec, blocks, s](hipEvent_t a, hipEvent_t b) {
+        const u32x4 *i_ = in; u32x4 *o_ = out; size_t n_ = nvec;
+        void *args[] = {&i_, &o_, &n_};
+        CK(hipExtLaunchKernel(reinterpret_cast<const void *>(copy_phased_kernel<UN, THREADS, TBITS>), dim3(blocks), dim3(THREADS),
+                              args, 0, s, a, b, 0));
+    };
+    L.v.push_back(v);
+}
+
+template <int LDM, int STM>
+static void add_policy(Lab &L, int wg_per_cu)
+{
+    int blocks = L.cus * wg_per_cu;
+    blocks -= blocks % 8;
+    char name[64];
+    snprintf(name, sizeof name, "copy_policy_ld%d_st%d_wg%d", LDM, STM, wg_per_cu);
+    const u32x4 *in = (const u32x4 *)L.pA.esa;
+    u32x4 *out = (u32x4 *)L.outs[0];
+    size_t nvec = L.pA.npix / 16;
+    Variant v;
+    v.name = name; v.blocks = blocks; v.threads = 256; v.bytes = 2.0 * L.pA.npix; v.check = nullptr;
+    hipStream_t s = L.s;
+    v.launch = [in, out, nvec, blocks, s](hipEvent_t a, hipEvent_t b) {
+        const u32x4 *i_ = in; u32x4 *o_ = out; size_t n_ = nvec;
+        void *args[] = {&i_, &o_, &n_};
+        CK(hipExtLaunchKernel(reinterpret_cast<const void *>(copy_policy_kernel<LDM, STM>), dim3(blocks), dim3(256), args, 0, s,
+                              a, b, 0));
     };
     L.v.push_back(v);
 }
@@ -496,6 +620,18 @@ int main(int argc, char **argv)
         add_variant<0, 2, true, 256, 1>(L, 8);              // timing only: no gather / no soil load / neither
         add_variant<0, 2, true, 256, 2>(L, 8);
         add_variant<0, 2, true, 256, 3>(L, 8);
+    }
+    else if (!strcmp(set, "policy")) {
+        add_copy<2, 256, 1>(L, 8);
+        add_policy<0, 1>(L, 8); add_policy<0, 2>(L, 8); add_policy<0, 3>(L, 8); add_policy<0, 4>(L, 8);
+        add_policy<1, 1>(L, 8); add_policy<1, 2>(L, 8); add_policy<2, 2>(L, 8); add_policy<2, 3>(L, 8);
+        add_copy<2, 256, 1>(L, 8);
+    }
+    else if (!strcmp(set, "phased")) {
+        add_copy<2, 256, 1>(L, 8); add_copy<4, 256, 1>(L, 8); add_copy<2, 256, 1>(L, 4);
+        add_phased<2, 256, 6>(L, 8); add_phased<2, 256, 7>(L, 8); add_phased<2, 256, 8>(L, 8); add_phased<2, 256, 9>(L, 8);
+        add_phased<4, 256, 7>(L, 8); add_phased<4, 256, 8>(L, 8); add_phased<4, 256, 9>(L, 8); add_phased<4, 256, 10>(L, 8);
+        add_phased<8, 256, 8>(L, 4); add_phased<8, 256, 9>(L, 4); add_phased<8, 256, 10>(L, 4);
     }
     else {      // "check": correctness of the odd-width paths
         add_variant<0, 2, true, 256, 0>(L, 8);
