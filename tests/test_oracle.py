@@ -300,3 +300,16 @@ def test_golden_fixture_regression(tables):
         out = oc.process_block_mem(esa, gt, coarse, sgt, tables)
         for r in range(18):
             assert hashlib.sha256(out[r].tobytes()).hexdigest() == case["sha256"][r], (case, r)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (37, 131, 3, 7), (64, 1041, 5, 44), (3, 5000, 2, 201)])
+def test_fused_best_cpu_pass_equals_reference_shaped_pass(shape):
+    """oracle/cn_fused_cpu.c (bench.py's cpu_baseline.best_cpu line, built -march=native on the host it
+    runs on) against oracle_process_block_subset, byte for byte, incl. awkward table values and subsets."""
+    H, W, hy, hx = shape
+    t = random_tables(3, 9)
+    esa, gt, coarse, sgt = make_block(H * 31 + W, H, W, hy, hx, nasty=True)
+    for cm, tm in [(3, 0x1FF), (1, 0x80), (2, 0x0A5)]:
+        a = oc.process_block_mem(esa, gt, coarse, sgt, t, cond_mask=cm, table_mask=tm)
+        b = oc.fused_block(esa, gt, coarse, sgt, t, cond_mask=cm, table_mask=tm)
+        assert np.array_equal(a, b), (shape, cm, tm)
