@@ -247,7 +247,7 @@ def main(argv=None):
                          "its rows (rows are independent given cj[], src/cn.c:218-232)")
     ap.add_argument("--no-tune", action="store_true",
                     help="skip the placement / launch-shape calibration of the one-raster workload")
-    ap.add_argument("--tune-arenas", type=int, default=6,
+    ap.add_argument("--tune-arenas", type=int, default=10,
                     help="candidate allocations the calibration chooses the raster buffer from")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="rehearsal: let ranks share GPUs (rank r uses device r mod visible devices)")

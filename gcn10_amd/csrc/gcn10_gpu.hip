@@ -508,55 +508,77 @@ __global__ __launch_bounds__(kThreads) void cn_strip_bytes(const StripParams p,
 // x-expansion of the coarse soil window (the x half of src/cn.c:218-232):
 // hx[r][x] = soil_code(coarse[r][ci[x]]) for every coarse row r.
 // ------------------------------------------------------------------------
+constexpr uint32_t kExpandRows = 2;     // coarse rows per thread of expand_x_codes
+
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void expand_x_codes(const uint8_t *coarse,
                                                            uint32_t hsx, uint32_t hsy,
                                                            const int32_t *ci, uint32_t W,
                                                            uint8_t *hx, uint32_t hx_stride)
 {
-    // one thread = 16 consecutive fine columns of one coarse row: 4 index loads
-    // (dwordx4 when ci is 16-byte aligned), 16 byte gathers that hit L1/L2 (a
-    // coarse row is ~1.4 KB), one 16-byte store
+    // one thread = 16 consecutive fine columns of kExpandRows coarse rows: the 16 column indices are
+    // loaded once (dwordx4 when ci is 16-byte aligned) and clamped once, then per row 16 byte gathers
+    // that hit L1/L2 (a coarse row is ~1.4 KB) and one 16-byte store
     const uint32_t x = (blockIdx.x * blockDim.x + threadIdx.x) * 16u;
-    const uint32_t r = blockIdx.y;
-    if (x >= hx_stride || r >= hsy)
+    const uint32_t r0 = blockIdx.y * kExpandRows;
+    if (x >= hx_stride || r0 >= hsy)
         return;
-    const uint8_t *row = coarse + (size_t)r * hsx;
     const uint8_t pad = (uint8_t)(kInvalidPlane | (kInvalidPlane << 4));
-    u32x4 o;
+    uint32_t cx[16];
     if (VEC && x + 16u <= W) {
         const u32x4 *civ = reinterpret_cast<const u32x4 *>(ci + x);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const u32x4 c4 = civ[j];
-            uint32_t w = 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t cx = c4[q];
-                w |= (uint32_t)soil_code(row[cx < hsx ? cx : hsx - 1u]) << (8 * q);
-            }
-            o[j] = w;
+            for (int q = 0; q < 4; q++)
+                cx[4 * j + q] = c4[q] < hsx ? c4[q] : hsx - 1u;
         }
     }
     else {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            uint32_t w = 0;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                // columns past W are padding: give them the "invalid" code
-                uint8_t code = pad;
-                const uint32_t xx = x + 4 * j + q;
-                if (xx < W) {
-                    const uint32_t cx = (uint32_t)ci[xx];
-                    code = soil_code(row[cx < hsx ? cx : hsx - 1u]);
-                }
-                w |= (uint32_t)code << (8 * q);
-            }
-            o[j] = w;
+        for (int q = 0; q < 16; q++) {
+            // columns past W are padding: marked here, given the "invalid" code below
+            const uint32_t xx = x + q;
+            const uint32_t c = xx < W ? (uint32_t)ci[xx] : 0xffffffffu;
+            cx[q] = c == 0xffffffffu ? c : (c < hsx ? c : hsx - 1u);
         }
     }
-    *reinterpret_cast<u32x4 *>(hx + (size_t)r * hx_stride + x) = o;
+    // the column map is monotone, and at the usual ratio (25 fine columns per coarse cell) 16 consecutive
+    // columns see at most two coarse cells: two byte loads and 16 selects instead of 16 byte gathers
+    // (the kernel is bound by the number of load instructions, not by bytes)
+    const uint32_t c_lo = cx[0], c_hi = cx[15];
+    const bool two = c_lo != 0xffffffffu && c_hi != 0xffffffffu && c_hi - c_lo <= 1u;
+    const uint32_t r1 = r0 + kExpandRows < hsy ? r0 + kExpandRows : hsy;
+    for (uint32_t r = r0; r < r1; r++) {
+        const uint8_t *row = coarse + (size_t)r * hsx;
+        u32x4 o;
+        if (two) {
+            const uint32_t code_lo = soil_code(row[c_lo]), code_hi = soil_code(row[c_hi]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    w |= (cx[4 * j + q] == c_lo ? code_lo : code_hi) << (8 * q);
+                o[j] = w;
+            }
+        }
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t c = cx[4 * j + q];
+                    const uint8_t code = c == 0xffffffffu ? pad : soil_code(row[c]);
+                    w |= (uint32_t)code << (8 * q);
+                }
+                o[j] = w;
+            }
+        }
+        *reinterpret_cast<u32x4 *>(hx + (size_t)r * hx_stride + x) = o;
+    }
 }
 
 __global__ __launch_bounds__(kThreads) void resample_rows(const uint8_t *coarse,
@@ -1283,7 +1305,7 @@ int gcn10_gpu_prepare_tile(gcn10_gpu_ctx *ctx, const uint8_t *coarse, int hsx, i
     ctx->hx_stride = stride;
     ctx->hx_W = (uint32_t)W;
     ctx->hx_rows = (uint32_t)hsy;
-    dim3 grid((stride / 16 + kThreads - 1) / kThreads, (uint32_t)hsy);
+    dim3 grid((stride / 16 + kThreads - 1) / kThreads, ((uint32_t)hsy + kExpandRows - 1) / kExpandRows);
     if (aligned16(ci))
         hipLaunchKernelGGL(expand_x_codes<true>, grid, dim3(kThreads), 0, as_stream(ctx, stream),
                            coarse, (uint32_t)hsx, (uint32_t)hsy, ci, (uint32_t)W, ctx->d_hx, stride);

@@ -506,3 +506,26 @@ def test_lookup_subset_of_several_tables_and_both_conditions(tmp_path, tables):
         for k, name in ((0, "p_i"), (5, "f_iii"), (7, "g_ii")):
             got = np.array(Image.open(str(tmp_path / ("cn_rasters_%s" % cond) / ("cn_%s_102.tif" % name))))
             assert np.array_equal(got, want[c * 9 + k]), (cond, name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gpu_deflate", [1, 0], ids=["gpu-deflate", "host-zlib"])
+def test_wide_block_through_the_vector_strip_kernels(tmp_path, tables, gpu_deflate):
+    """A block 1237 px wide (odd: rows not 16-byte aligned) in the two modes that materialise CN strips:
+    the 16-byte-per-lane strip kernels run (blocks under 1040 px take the byte-wise kernel), strips of
+    256 rows start at multiples of 16 bytes, lanes straddle row ends."""
+    esa, soil = _world(tmp_path, seed=21, extra_cfg="gpu_deflate=%d\n" % gpu_deflate)
+    tiffutil.write_block_shapefile(str(tmp_path / "blocks"), [(301, 10.5, 48.9, 11.737, 49.9)])
+    (tmp_path / "ids.txt").write_text("301\n")
+    out = _run(tmp_path, "-c", "config.txt", "-l", "ids.txt")
+    assert out.returncode == 0, out.stderr[-2000:]
+    bbox = [10.5, 48.9, 11.737, 49.9]
+    xo, yo, W, H, gt = oc.window(ESA_GT, 3000, 2000, bbox)
+    assert W == 1237 and H == 1000
+    sxo, syo, hsx, hsy, sgt = oc.window(SOIL_GT, soil.shape[1], soil.shape[0], bbox)
+    want = oc.process_block_mem(esa[yo:yo + H, xo:xo + W], gt, soil[syo:syo + hsy, sxo:sxo + hsx], sgt, tables)
+    for c, cond in enumerate(CONDS):
+        for hi, hc in enumerate(HCS):
+            for ai, arc in enumerate(ARCS):
+                p = tmp_path / ("cn_rasters_%s" % cond) / ("cn_%s_%s_301.tif" % (hc, arc))
+                assert np.array_equal(np.array(Image.open(str(p))), want[c * 9 + hi * 3 + ai]), p

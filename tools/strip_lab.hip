@@ -200,6 +200,26 @@ __global__ __launch_bounds__(THREADS) void lab_kernel(const P p)
 
     // every XCD (blockIdx % 8) streams a contiguous eighth of the trips
     const uint32_t nb = gridDim.x, b = blockIdx.x;
+    if (MAP == 2) {
+        // region-synchronous sub-slabs: the strip is cut at multiples of 64 MiB of the landcover's ADDRESS;
+        // every region is split into eight sub-slabs, one per XCD, and all XCDs sweep one region at a time,
+        // so that at any moment all reads fall into one 64 MiB-aligned piece of memory
+        constexpr uint32_t kTripBytes = THREADS * 16 * ILP;
+        constexpr uint32_t kRegionTrips = (64u << 20) / kTripBytes, kSubTrips = kRegionTrips / 8u;
+        const uint32_t phase = (uint32_t)(((uintptr_t)p.esa & ((64u << 20) - 1u)) / kTripBytes);
+        const uint32_t xcd = b & 7u, first = b >> 3, step = nb / 8u;
+        const uint32_t nregions = (p.ntrips + phase + kRegionTrips - 1u) / kRegionTrips;
+        for (uint32_t r = 0; r < nregions; r++)
+            for (uint32_t t = first; t < kSubTrips; t += step) {
+                const uint32_t g = r * kRegionTrips + xcd * kSubTrips + t;
+                if (g < phase || g - phase >= p.ntrips)
+                    continue;
+                Trip<ILP> tr;
+                issue<LUTK, ILP, THREADS, DIAG, NTM>(p, g - phase, lane16, wave, tr);
+                finish<LUTK, ILP, DIAG, NTM>(p, lut, lane_rep, tr);
+            }
+    }
+    else {
     const uint32_t per = (p.ntrips + 7u) / 8u;
     const uint32_t lo = (b & 7u) * per;
     const uint32_t end = MAP ? (lo + per < p.ntrips ? lo + per : p.ntrips) : p.ntrips;
@@ -233,6 +253,7 @@ __global__ __launch_bounds__(THREADS) void lab_kernel(const P p)
             finish<LUTK, ILP, DIAG, NTM>(p, lut, lane_rep, tb);
         }
     }
+    }
     // the last npix % 16 pixels, byte-wise
     if (blockIdx.x == 0 && threadIdx.x < (p.npix & 15u) && !(DIAG & 3)) {
         const uint32_t i = p.nvec * 16u + threadIdx.x;
@@ -254,6 +275,32 @@ template <int UN, int THREADS, int MAP = 1>
 __global__ __launch_bounds__(THREADS) void copy_kernel(const u32x4 *in, u32x4 *out, size_t nvec)
 {
     const size_t nchunk = (nvec + THREADS * UN - 1) / (THREADS * UN);
+    if (MAP == 2) {
+        constexpr uint32_t kChunkBytes = THREADS * 16 * UN;
+        constexpr uint32_t kRegion = (64u << 20) / kChunkBytes, kSub = kRegion / 8u;
+        const uint32_t phase = (uint32_t)(((uintptr_t)in & ((64u << 20) - 1u)) / kChunkBytes);
+        const uint32_t xcd = blockIdx.x & 7u, first = blockIdx.x >> 3, step = gridDim.x / 8u;
+        const uint32_t nregions = (uint32_t)((nchunk + phase + kRegion - 1u) / kRegion);
+        for (uint32_t r = 0; r < nregions; r++)
+            for (uint32_t t = first; t < kSub; t += step) {
+                const uint32_t g = r * kRegion + xcd * kSub + t;
+                if (g < phase || g - phase >= nchunk)
+                    continue;
+                const size_t c = g - phase;
+                u32x4 v[UN];
+                size_t idx[UN];
+#pragma unroll
+                for (int u = 0; u < UN; u++) {
+                    idx[u] = (c * UN + u) * THREADS + threadIdx.x;
+                    v[u] = __builtin_nontemporal_load(in + (idx[u] < nvec ? idx[u] : 0));
+                }
+#pragma unroll
+                for (int u = 0; u < UN; u++)
+                    if (idx[u] < nvec)
+                        __builtin_nontemporal_store(v[u], out + idx[u]);
+            }
+        return;
+    }
     const size_t per = (nchunk + 7) / 8, xcd = blockIdx.x & 7;
     size_t c = MAP ? xcd * per + (blockIdx.x >> 3) : blockIdx.x;
     const size_t cend = MAP ? ((xcd + 1) * per < nchunk ? (xcd + 1) * per : nchunk) : nchunk;
@@ -620,6 +667,17 @@ int main(int argc, char **argv)
         add_variant<0, 2, true, 256, 1>(L, 8);              // timing only: no gather / no soil load / neither
         add_variant<0, 2, true, 256, 2>(L, 8);
         add_variant<0, 2, true, 256, 3>(L, 8);
+    }
+    else if (!strcmp(set, "regions")) {
+        // the same copies / kernels into three allocations: slabs vs grid-stride vs region-synchronous sub-slabs
+        add_copy<2, 256, 1>(L, 8); add_copy<2, 256, 0>(L, 8); add_copy<2, 256, 2>(L, 8); add_copy<2, 256, 2>(L, 16);
+        add_copy<4, 256, 2>(L, 8);
+        for (int o = 0; o < 3; o++) {
+            add_variant<0, 2, true, 256, 0, 1>(L, 8, o);
+            add_variant<0, 2, false, 256, 0, 2>(L, 8, o);
+            add_variant<0, 4, false, 256, 0, 2>(L, 8, o);
+            add_variant<0, 4, false, 256, 0, 1>(L, 16, o);
+        }
     }
     else if (!strcmp(set, "policy")) {
         add_copy<2, 256, 1>(L, 8);
