@@ -43,9 +43,13 @@ using gcn10::use_device;
 
 namespace {
 
-constexpr int kWindow = 32768;
+// The LDS ring holds the last 16 KiB of output; DEFLATE distances reach 32 KiB, and the rare match that
+// starts further back than the ring reaches is read from the tile's slot in HBM, where every byte
+// older than kFlush + 258 already is (copy_match).  16 KiB instead of 32 lets six streams share a CU
+// (a block's ~1300-1370 tiles then decode in one round of 1536 slots instead of 1024 + a ragged rest).
+constexpr int kWindow = 16384;
 constexpr int kWindowMask = kWindow - 1;
-constexpr int kFlush = 16384;
+constexpr int kFlush = 8192;
 constexpr int kBatch = 64;              // token words per hand-over from the decoder to the copier
 constexpr int kLitRoot = 10;
 constexpr int kDistRoot = 9;
@@ -396,7 +400,25 @@ __device__ __forceinline__ void flush_half(Shared &sh, Output &o, int lane)
 __device__ __forceinline__ void copy_match(Shared &sh, Output &o, uint32_t len, uint32_t dist, int lane)
 {
     const uint32_t from = o.pos - dist;
-    if (len <= 64u && dist >= len) {
+    if (dist + len > (uint32_t)kWindow) {
+        // the source starts before what the ring still holds (its oldest bytes are overwritten as this
+        // copy proceeds): all of it has been flushed to the slot (from + len <= pos - kWindow + 2 len
+        // <= flushed, since pos - flushed < kFlush + 258) -- wait for those stores, read it back
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint8_t v[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const uint32_t k = (uint32_t)lane + 64u * (uint32_t)i;
+            v[i] = k < len ? o.out[from + k] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const uint32_t k = (uint32_t)lane + 64u * (uint32_t)i;
+            if (k < len)
+                sh.window[(o.pos + k) & kWindowMask] = v[i];
+        }
+    }
+    else if (len <= 64u && dist >= len) {
         // the usual case: one step, source and destination apart
         if ((uint32_t)lane < len)
             sh.window[(o.pos + (uint32_t)lane) & kWindowMask] = sh.window[(from + (uint32_t)lane) & kWindowMask];
@@ -1012,7 +1034,7 @@ int gcn10_gpu_inflate_tiles(gcn10_gpu_ctx *ctx, const uint8_t *comp_dev, const g
         HIP_TRY(hipMalloc(&ctx->inflate_ws, need));
         ctx->inflate_ws_cap = need;
     }
-    static_assert(sizeof(Shared) <= 40 * 1024, "four streams (eight wavefronts) per CU");
+    static_assert(sizeof(Shared) <= 26 * 1024, "six streams (twelve wavefronts) per CU of 160 KiB LDS");
     hipStream_t s = as_stream(ctx, stream);
     uint8_t *scratch = reinterpret_cast<uint8_t *>(ctx->inflate_ws);
     hipLaunchKernelGGL(inflate_kernel, dim3((uint32_t)n_tiles), dim3(128), sizeof(Shared), s, comp_dev,
