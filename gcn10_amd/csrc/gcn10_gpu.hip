@@ -1376,7 +1376,15 @@ int gcn10_gpu_cn_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, int rows,
     if (!all_aligned) {
         p.lut = ctx->d_lut16;
         const uint32_t g = stream_grid(ctx, ((uint64_t)p.npix + kThreads - 1) / kThreads);
-        hipLaunchKernelGGL(cn_strip_bytes, dim3(g), dim3(kThreads), 0, s, p, cond_mask);
+        if (ctx->time_start && ctx->time_stop) {
+            void *args[] = { &p, &cond_mask };
+            HIP_TRY(hipExtLaunchKernel(reinterpret_cast<const void *>(cn_strip_bytes), dim3(g), dim3(kThreads), args, 0,
+                                       s, ctx->time_start, ctx->time_stop, 0));
+            ctx->time_start = ctx->time_stop = nullptr;
+        }
+        else {
+            hipLaunchKernelGGL(cn_strip_bytes, dim3(g), dim3(kThreads), 0, s, p, cond_mask);
+        }
         ctx->last_kernel = "cn_strip_bytes";
     }
     else {
