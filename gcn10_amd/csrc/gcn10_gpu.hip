@@ -1458,6 +1458,7 @@ int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value)
         ctx->prefetch = fresh.prefetch;
         ctx->deflate_wave_codes = fresh.deflate_wave_codes;
         ctx->fused_diag = fresh.fused_diag;
+        ctx->inflate_diag = fresh.inflate_diag;
         ctx->single = fresh.single;
     }
     else if (!strcmp(name, "grid_blocks_per_cu") && value >= 1 && value <= 64)
@@ -1476,6 +1477,8 @@ int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value)
         ctx->deflate_wave_codes = value;
     else if (!strcmp(name, "fused_diag") && value >= 0 && value < 8)
         ctx->fused_diag = value;
+    else if (!strcmp(name, "inflate_diag") && value >= 0 && value < 4)
+        ctx->inflate_diag = value;
     else if (!strcmp(name, "prefetch") && (value == -1 || value == 0 || value == 1))
         ctx->prefetch = value;
     else

@@ -67,6 +67,7 @@ struct gcn10_gpu_ctx {
     int deflate_wave_codes = 1;     // pass B of the tile encoder: 1 = one wave per tile, 0 = one thread
     int fused_diag = 0;             // timing experiments only (streams become invalid): 2 = pass F-C
                                     // without its token trips (set-up cost alone)
+    int inflate_diag = 0;           // timing experiments only (output invalid): 1 = copier idle, 2 = empty batches
     bool fused_ready = false;
     bool codes_ready = false;       // LDS attribute of the per-thread code construction set
     bool deflate_ready = false;     // LDS attributes of the tile encoder set on this device

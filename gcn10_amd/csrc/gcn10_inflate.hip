@@ -51,6 +51,7 @@ constexpr int kWindow = 16384;
 constexpr int kWindowMask = kWindow - 1;
 constexpr int kFlush = 8192;
 constexpr int kBatch = 64;              // token words per hand-over from the decoder to the copier
+constexpr int kCand = 4;               // candidate start bits per lane: a window of 64 * kCand bits
 constexpr int kLitRoot = 10;
 constexpr int kDistRoot = 9;
 
@@ -185,6 +186,34 @@ __device__ __forceinline__ uint32_t reader_byte_pos(const Reader &r)
 __device__ __forceinline__ uint32_t uniform(uint32_t v)
 {
     return __builtin_amdgcn_readfirstlane(v);
+}
+
+// Inclusive prefix sum over the 64 lanes with DPP adds.
+__device__ __forceinline__ uint32_t wave_scan(uint32_t x)
+{
+    uint32_t r = x;
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);     // row_shr:1
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);     // row_shr:2
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x113, 0xf, 0xf, false);     // row_shr:3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x114, 0xf, 0xe, false);     // row_shr:4, lanes 4..15
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x118, 0xf, 0xc, false);     // row_shr:8, lanes 8..15
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
+    return r;
+}
+
+// Sum over the 64 lanes, wave-uniform, with DPP adds (no LDS round trips): quads, rows of 16, then
+// row_bcast:15 / row_bcast:31 carry the row totals to lane 63.
+__device__ __forceinline__ uint32_t wave_total(uint32_t x)
+{
+    uint32_t r = x;
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0xb1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x4e, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x141, 0xf, 0xf, false);     // row_half_mirror
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x140, 0xf, 0xf, false);     // row_mirror
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)r, 63);
 }
 
 // Sorts the n symbols of lens[] by (length, symbol) and derives first code / offset per
@@ -397,13 +426,16 @@ __device__ __forceinline__ void flush_half(Shared &sh, Output &o, int lane)
     o.flushed += kFlush;
 }
 
-__device__ __forceinline__ void copy_match(Shared &sh, Output &o, uint32_t len, uint32_t dist, int lane)
+// `ahead`: bytes of the ring from this token's first byte up to the furthest byte already written (the
+// token's own length when tokens are carried out strictly in order; more when later tokens of the
+// sub-batch have been carried out first): the ring bytes that far behind have been overwritten.
+__device__ __forceinline__ void copy_match(Shared &sh, Output &o, uint32_t len, uint32_t dist, uint32_t ahead, int lane)
 {
     const uint32_t from = o.pos - dist;
-    if (dist + len > (uint32_t)kWindow) {
-        // the source starts before what the ring still holds (its oldest bytes are overwritten as this
-        // copy proceeds): all of it has been flushed to the slot (from + len <= pos - kWindow + 2 len
-        // <= flushed, since pos - flushed < kFlush + 258) -- wait for those stores, read it back
+    if (dist + ahead > (uint32_t)kWindow) {
+        // the source starts before what the ring still holds: all of it has been flushed to the slot
+        // (from + len <= pos - kWindow + ahead + len <= flushed, since pos - flushed < kFlush + 4096 and
+        // ahead <= kSubCap) -- wait for those stores, read it back
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint8_t v[5];
 #pragma unroll
@@ -702,8 +734,9 @@ __device__ __forceinline__ bool scalar_token(Shared &sh, Decoder &d, uint32_t *r
 // produces output and output is bounded, every header consumes input and input is bounded, so
 // the stream ends (d.state = kDone) whatever its bits are.
 //
-// Inside a block the 64 lanes decode SPECULATIVELY: lane k decodes the token that would start at
-// bit P + k (table lookups as gathers, all in vector registers), and a scalar walk then follows
+// Inside a block the 64 lanes decode SPECULATIVELY: lane k decodes the tokens that would start at
+// bits P + k, P + 64 + k, ... of a 256-bit window (table lookups as gathers, all in vector
+// registers; 8 bits of result per candidate, packed four to a register), and a scalar walk then follows
 // the real chain -- start at lane 0, jump by each token's bit count -- collecting the tokens it
 // passes.  The serial part of the decode is that walk: one v_readlane and a few scalar
 // instructions per token instead of two dependent table lookups.
@@ -745,38 +778,39 @@ __device__ __forceinline__ uint32_t decode_batch(Shared &sh, Decoder &d, uint32_
             }
             continue;
         }
-        // ---- kInSymbols: one window of 128 candidate start bits at d.P, two per lane ----
+        // ---- kInSymbols: one window of 256 candidate start bits at d.P, four per lane ----
         const uint32_t q0 = d.P >> 5;
         ensure_piece(r, q0 >> 6);
-        uint32_t D[7];
-        if ((q0 & 63u) <= 57u) {
-            // the usual case: all seven dwords in one piece, one select for all of them
+        uint32_t D[11];
+        if ((q0 & 63u) <= 53u) {
+            // the usual case: all eleven dwords in one piece, one select for all of them
             const uint32_t piece = (q0 >> 6) == r.chunk ? r.cur : r.prv;
             const int l0 = (int)(q0 & 63u);
 #pragma unroll
-            for (int i = 0; i < 7; i++)
+            for (int i = 0; i < 11; i++)
                 D[i] = (uint32_t)__builtin_amdgcn_readlane((int)piece, l0 + i);
         }
         else {
 #pragma unroll
-            for (int i = 0; i < 7; i++)
+            for (int i = 0; i < 11; i++)
                 D[i] = stream_dword(r, q0 + (uint32_t)i);
         }
         const uint32_t rel = (d.P & 31u) + (uint32_t)lane;          // < 95
         const uint32_t o = rel >> 5, sft = rel & 31u;
-        uint32_t info[2], tok[2];
+        uint32_t tok[kCand];
+        uint32_t packed = 0;        // per candidate 8 bits: bits it takes (< 64) | stop reason << 6
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
-            // candidate at bit lane + 64 * half: dwords o + 2 * half .. + 2 of the seven
-            const uint32_t a = o == 0 ? D[2 * half] : o == 1 ? D[2 * half + 1] : D[2 * half + 2];
-            const uint32_t b = o == 0 ? D[2 * half + 1] : o == 1 ? D[2 * half + 2] : D[2 * half + 3];
-            const uint32_t c = o == 0 ? D[2 * half + 2] : o == 1 ? D[2 * half + 3] : D[2 * half + 4];
+        for (int h = 0; h < kCand; h++) {
+            // candidate at bit lane + 64 * h: dwords o + 2 * h .. + 2 of the eleven
+            const uint32_t a = o == 0 ? D[2 * h] : o == 1 ? D[2 * h + 1] : D[2 * h + 2];
+            const uint32_t b = o == 0 ? D[2 * h + 1] : o == 1 ? D[2 * h + 2] : D[2 * h + 3];
+            const uint32_t c = o == 0 ? D[2 * h + 2] : o == 1 ? D[2 * h + 3] : D[2 * h + 4];
             const uint32_t lo = __builtin_amdgcn_alignbit(b, a, sft);   // bits of the candidate .. +31
             const uint32_t hi = __builtin_amdgcn_alignbit(c, b, sft);   //                     +32 .. +63
             const uint32_t e1 = sh.lit_tab[lo & ((1u << kLitRoot) - 1u)];
             const uint32_t cl = e1 & 15u, kind = (e1 >> 4) & 3u;
-            uint32_t bits = cl, outl = (e1 >> 6) & 3u;
-            uint32_t tk = outl << 24 | (e1 >> 8);
+            uint32_t bits = cl;
+            uint32_t tk = ((e1 >> 6) & 3u) << 24 | (e1 >> 8);
             uint32_t special = e1 == 0 ? 2u : (kind == (uint32_t)kEndOfBlock ? 1u : 0u);
             {
                 // as if it were a match (harmless where it is not: the lookups stay in the tables)
@@ -789,41 +823,64 @@ __device__ __forceinline__ uint32_t decode_batch(Shared &sh, Decoder &d, uint32_
                 const uint32_t dist = ((de >> 8) & 0xffffu) + ((x2 >> dl) & ((1u << deb) - 1u));
                 if (kind == (uint32_t)kLength && e1 != 0) {
                     bits = t + dl + deb;                                // <= 48
-                    outl = len;
                     tk = kTokMatch | ((len - 3u) & 255u) << 16 | ((dist - 1u) & 0xffffu);
                     if (de == 0)
                         special = 2u;
                 }
             }
-            // bits | bytes produced << 6 for a token the walk passes; reason << 15 for one it stops
-            // at: an end of block (with its bits, which the walk takes) or a code the tables do not
-            // hold (no bits: the scalar reader starts at it)
-            info[half] = special == 2u ? 2u << 15 : special == 1u ? (cl | 1u << 15) : (bits | outl << 6);
-            tok[half] = tk;
+            // a token the walk passes: its bits; one it stops at: an end of block (with its bits,
+            // which the walk takes) or a code the tables do not hold (no bits: the scalar reader
+            // starts at it)
+            const uint32_t inf8 = special == 2u ? 0x80u : special == 1u ? (cl | 0x40u) : bits;
+            packed |= inf8 << (8 * h);
+            tok[h] = tk;
         }
         // ---- the chain: from bit 0 of the window, token by token.  One exit, no branches in the
-        // body: the loop is the serial core of the decoder ----
-        uint32_t k = 0, n_new = 0, src = 0, stop = 0;
+        // body, one v_readlane per token: the loop is the serial core of the decoder.  The bytes the
+        // tokens produce are summed afterwards (they are in the token words) ----
+        uint32_t k = 0, n_new = 0, src = 0, stop = 0, last_bits = 0;
         const uint32_t room = (uint32_t)kBatch - n;
         bool go = true;
         while (go) {
-            const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane((int)info[0], (int)(k & 63u));
-            const uint32_t i1 = (uint32_t)__builtin_amdgcn_readlane((int)info[1], (int)(k & 63u));
-            const uint32_t inf = k < 64u ? i0 : i1;
+            const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)(k & 63u));
+            const uint32_t inf = (pk >> ((k >> 6) * 8u)) & 0xffu;
             src = (uint32_t)lane == n_new ? k : src;    // (a stop token's entry lies beyond n_new: unused)
-            n_new += inf < 0x8000u ? 1u : 0u;
-            d.pos += (inf >> 6) & 511u;
-            k += inf & 63u;
-            stop = inf >> 15;
-            go = (stop == 0u) & (d.pos < d.limit) & (n_new < room) & (k < 128u);
+            n_new += inf < 0x40u ? 1u : 0u;
+            last_bits = inf & 63u;
+            k += last_bits;
+            stop = inf >> 6;
+            go = (stop == 0u) & (n_new < room) & (k < 64u * (uint32_t)kCand);
         }
-        if (stop == 0u && d.pos >= d.limit)
-            stop = 4u;
         {
-            const uint32_t m0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src & 63u) << 2), (int)tok[0]);
-            const uint32_t m1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src & 63u) << 2), (int)tok[1]);
-            if ((uint32_t)lane < n_new)
-                ring[n + (uint32_t)lane] = src < 64u ? m0 : m1;
+            const int sel = (int)((src & 63u) << 2);
+            uint32_t mine = 0;
+#pragma unroll
+            for (int h = 0; h < kCand; h++) {
+                const uint32_t m = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)tok[h]);
+                mine = (src >> 6) == (uint32_t)h ? m : mine;
+            }
+            const bool kept = (uint32_t)lane < n_new;
+            if (kept)
+                ring[n + (uint32_t)lane] = mine;
+            // bytes of the kept tokens: a match says its length, literals their count
+            const uint32_t outl = !kept ? 0u : (mine & kTokMatch) ? ((mine >> 16) & 255u) + 3u : (mine >> 24);
+            const uint32_t total = wave_total(outl);
+            if (d.pos + total >= d.limit) {
+                // the tile ends inside this window (once per stream): keep the tokens up to the one
+                // that reaches the limit and stand behind it, exactly -- nothing behind it counts, not
+                // even the end-of-block code the walk may have taken
+                const uint32_t cum = wave_scan(outl);
+                const uint32_t before = (uint32_t)__builtin_popcountll(__ballot(kept && d.pos + cum < d.limit));
+                const uint32_t keep = before + 1u < n_new ? before + 1u : n_new;
+                const uint32_t k_next = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)(keep & 63u));
+                k = keep < n_new ? k_next : (stop == 1u ? k - last_bits : k);
+                d.pos += (uint32_t)__builtin_amdgcn_readlane((int)cum, (int)((keep - 1u) & 63u));
+                n_new = keep;
+                stop = 4u;
+            }
+            else {
+                d.pos += total;
+            }
             n += n_new;
         }
         d.P += k;
@@ -852,9 +909,9 @@ __device__ __forceinline__ uint32_t decode_batch(Shared &sh, Decoder &d, uint32_
     return n;
 }
 
-// The copier wave: carries out a batch of tokens on the window and sends finished halves to HBM.
+// A batch of tokens carried out one by one, in order (batches that hold a stored run).
 // Returns 0, or the reason a token cannot be carried out (a distance before the start).
-__device__ __forceinline__ uint32_t copy_batch(Shared &sh, Output &o, const uint32_t *ring, uint32_t n,
+__device__ __forceinline__ uint32_t copy_batch_serial(Shared &sh, Output &o, const uint32_t *ring, uint32_t n,
                                                const uint8_t *stream, int lane)
 {
     const uint32_t tk = (uint32_t)lane < n ? ring[lane] : 0u;
@@ -869,7 +926,7 @@ __device__ __forceinline__ uint32_t copy_batch(Shared &sh, Output &o, const uint
                 return kErrDistance;
             if (len > o.limit - o.pos)
                 len = o.limit - o.pos;
-            copy_match(sh, o, len, dist, lane);
+            copy_match(sh, o, len, dist, len, lane);
         }
         else if (a & kTokStored) {
             const uint32_t len = a & 0xffffu;
@@ -891,10 +948,92 @@ __device__ __forceinline__ uint32_t copy_batch(Shared &sh, Output &o, const uint
     return 0;
 }
 
+// The copier wave: carries out a batch of tokens on the window and sends finished halves to HBM.
+// Returns 0, or the reason a token cannot be carried out (a distance before the start).
+//
+// One token per lane.  A prefix sum of the tokens' lengths gives every token its place; the batch is
+// taken in sub-batches of at most kSubCap bytes (the ring must keep what is not flushed yet), and in
+// each sub-batch
+//   A  all literal tokens write their 1..3 bytes at once,
+//   B  all short matches whose source lies wholly before the sub-batch (nothing in it can change
+//      their source) copy their bytes at once, one lane per token,
+//   C  the remaining matches are carried out one by one, in order, by all 64 lanes (copy_match).
+// A token carried out early only writes bytes of its own place, so the order of A, B and C among
+// tokens that do not read each other's output is free; C runs in stream order, and by then every
+// byte an earlier token produces is there.
+constexpr uint32_t kSubCap = 4096;
+constexpr uint32_t kShortMatch = 8;
+
+__device__ __forceinline__ uint32_t copy_batch(Shared &sh, Output &o, const uint32_t *ring, uint32_t n,
+                                               const uint8_t *stream, int lane)
+{
+    const uint32_t tk = (uint32_t)lane < n ? ring[lane] : 0u;
+    const bool valid = (uint32_t)lane < n;
+    if (__ballot(valid && !(tk & kTokMatch) && (tk & kTokStored)) != 0ull)
+        return copy_batch_serial(sh, o, ring, n, stream, lane);
+    const bool is_match = (tk & kTokMatch) != 0u;
+    const uint32_t dist = (tk & 0xffffu) + 1u;
+    uint32_t done = 0;
+    while (done < n && o.pos < o.limit) {
+        const bool in = valid && (uint32_t)lane >= done;
+        const uint32_t len = !in ? 0u : is_match ? ((tk >> 16) & 255u) + 3u : (tk >> 24);
+        const uint32_t incl = wave_scan(len);
+        const uint32_t off = incl - len;
+        const uint32_t m = (uint32_t)__builtin_popcountll(__ballot(in && incl <= kSubCap));    // >= 1
+        const bool mine = in && (uint32_t)lane < done + m;
+        const uint32_t S = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)((done + m - 1u) & 63u));
+        const uint32_t dst = o.pos + off;
+        // bytes wanted of this token: none behind the limit, the one that reaches it is cut
+        uint32_t l = !mine || dst >= o.limit ? 0u : (len < o.limit - dst ? len : o.limit - dst);
+        if (__ballot(is_match && l > 0u && dist > dst) != 0ull)
+            return kErrDistance;
+        const uint32_t ahead = S - off;                     // ring bytes written from dst on, once the sub-batch is out
+        const bool near = dist + ahead <= (uint32_t)kWindow;
+        const bool early = is_match && l > 0u && l <= kShortMatch && near && dist >= off + l;
+        // A: literals
+        if (!is_match && l > 0u) {
+#pragma unroll
+            for (uint32_t b = 0; b < 3u; b++)
+                if (b < l)
+                    sh.window[(dst + b) & kWindowMask] = (uint8_t)(tk >> (8u * b));
+        }
+        // B: short matches that read nothing of this sub-batch
+        {
+            uint8_t v[kShortMatch];
+#pragma unroll
+            for (uint32_t b = 0; b < kShortMatch; b++)
+                v[b] = early && b < l ? sh.window[(dst - dist + b) & kWindowMask] : (uint8_t)0;
+#pragma unroll
+            for (uint32_t b = 0; b < kShortMatch; b++)
+                if (early && b < l)
+                    sh.window[(dst + b) & kWindowMask] = v[b];
+        }
+        // C: the other matches, in order
+        unsigned long long rest = __ballot(is_match && l > 0u && !early);
+        const uint32_t pos0 = o.pos;
+        while (rest != 0ull) {
+            const int i = __builtin_ctzll(rest);
+            rest &= rest - 1ull;
+            o.pos = (uint32_t)__builtin_amdgcn_readlane((int)dst, i);
+            copy_match(sh, o, (uint32_t)__builtin_amdgcn_readlane((int)l, i),
+                       (uint32_t)__builtin_amdgcn_readlane((int)dist, i),
+                       (uint32_t)__builtin_amdgcn_readlane((int)ahead, i), lane);
+        }
+        o.pos = pos0 + S < o.limit ? pos0 + S : o.limit;
+        done += m;
+        if (o.pos - o.flushed >= (uint32_t)kFlush)
+            flush_half(sh, o, lane);
+    }
+    return 0;
+}
+
 // One workgroup of two wavefronts per stream: wave 0 decodes bits into tokens, wave 1 carries
 // the tokens out; they swap halves of a small token ring at a barrier every kBatch tokens.
+// diag (gcn10_gpu_set_option "inflate_diag", timing experiments only, output invalid): 1 = the copier
+// carries nothing out, 2 = the decoder hands over empty batches after decoding them
 __global__ __launch_bounds__(128) void inflate_kernel(const uint8_t *comp, const TileIn *tiles, uint32_t n_tiles,
-                                                      uint8_t *scratch, uint32_t slot_bytes, uint32_t *status)
+                                                      uint8_t *scratch, uint32_t slot_bytes, uint32_t *status,
+                                                      uint32_t diag)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Shared &sh = *reinterpret_cast<Shared *>(smem);
@@ -946,7 +1085,7 @@ __global__ __launch_bounds__(128) void inflate_kernel(const uint8_t *comp, const
             if (!announced) {
                 const uint32_t n = decode_batch(sh, d, sh.ring[cur], lane);
                 if (lane == 0)
-                    sh.count[cur] = n;
+                    sh.count[cur] = diag == 2u ? 0u : n;
                 if (d.state == (uint32_t)kDone) {
                     if (!d.err && reader_byte_pos(d.r) > d.in_len + 4u)
                         d.err = kErrInput;
@@ -959,7 +1098,8 @@ __global__ __launch_bounds__(128) void inflate_kernel(const uint8_t *comp, const
             }
         }
         else if (it > 0 && c_err == 0) {
-            c_err = copy_batch(sh, o, sh.ring[cur ^ 1u], uniform(sh.count[cur ^ 1u]), comp + tin.in_off, lane);
+            if (diag != 1u)
+                c_err = copy_batch(sh, o, sh.ring[cur ^ 1u], uniform(sh.count[cur ^ 1u]), comp + tin.in_off, lane);
         }
         __syncthreads();
         if (it >= uniform(sh.stop))
@@ -1038,7 +1178,8 @@ int gcn10_gpu_inflate_tiles(gcn10_gpu_ctx *ctx, const uint8_t *comp_dev, const g
     hipStream_t s = as_stream(ctx, stream);
     uint8_t *scratch = reinterpret_cast<uint8_t *>(ctx->inflate_ws);
     hipLaunchKernelGGL(inflate_kernel, dim3((uint32_t)n_tiles), dim3(128), sizeof(Shared), s, comp_dev,
-                       reinterpret_cast<const TileIn *>(tiles_dev), (uint32_t)n_tiles, scratch, slot, status_dev);
+                       reinterpret_cast<const TileIn *>(tiles_dev), (uint32_t)n_tiles, scratch, slot, status_dev,
+                       (uint32_t)ctx->inflate_diag);
     hipLaunchKernelGGL(untile_kernel, dim3((uint32_t)n_tiles, 16), dim3(256), 0, s,
                        reinterpret_cast<const TileIn *>(tiles_dev), scratch, slot, dst_dev,
                        (unsigned long long)dst_stride);

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--tiles-per-side", type=int, default=36)
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--diag", type=int, default=0, help="gcn10_gpu_set_option inflate_diag (timing only, output invalid)")
     a = ap.parse_args()
     T = 1024
     side = 6 * T
@@ -53,6 +54,8 @@ def main():
     with gpu.Engine(0) as e:
         bufs = [e.upload(comp), e.upload(tl.view(np.uint8)), e.alloc(W * W), e.alloc(4 * n)]
         e0, e1 = e.event_create(), e.event_create()
+        if a.diag:
+            e.set_option("inflate_diag", a.diag)
         ms = []
         for rep in range(a.reps + 1):
             e.event_record(e0)
