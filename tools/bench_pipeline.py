@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--gpu-deflate", type=int, default=2)
     ap.add_argument("--workers-per-gpu", type=int, default=0)
     ap.add_argument("--gpu-inflate", type=int, default=1)
+    ap.add_argument("--lookups", default="", help='config key "lookups" (e.g. g_ii): BASELINE config 3, single lookup')
+    ap.add_argument("--conditions", default="", help='config key "conditions" (drained | undrained | both)')
     ap.add_argument("--repeat", type=int, default=1,
                     help="list every block geometry this many times under different ids (long runs on a small world)")
     ap.add_argument("--dual-soil-fraction", type=float, default=-1.0,
@@ -66,9 +68,10 @@ def main():
     with open(os.path.join(wd, "config.txt"), "w") as f:
         f.write("hysogs_data_path=%s/soil.tif\nesa_data_path=%s/esa.tif\nblocks_shp_path=%s/blocks.shp\n"
                 "lookup_table_path=%s\nlog_dir=%s/logs\nstrip_rows=%d\ndeflate_level=%d\ngpu_deflate=%d\n"
-                "workers_per_gpu=%d\ngpu_inflate=%d\n"
+                "workers_per_gpu=%d\ngpu_inflate=%d\n%s%s"
                 % (wd, wd, wd, os.path.join(ROOT, "tests", "golden", "lookups"), wd, a.strip_rows,
-                   a.deflate_level, a.gpu_deflate, a.workers_per_gpu, a.gpu_inflate))
+                   a.deflate_level, a.gpu_deflate, a.workers_per_gpu, a.gpu_inflate,
+                   "lookups=%s\n" % a.lookups if a.lookups else "", "conditions=%s\n" % a.conditions if a.conditions else ""))
     build_s = time.time() - t0
     run_modes(a, wd, size, nb, build_s)
 
@@ -99,7 +102,11 @@ def build_world(a, wd, size, nb, px):
 
 
 def run_modes(a, wd, size, nb, build_s):
-    res = {"size": size, "blocks": nb, "strip_rows": a.strip_rows, "gpus": a.gpus, "pattern": a.pattern, "gpu_deflate": a.gpu_deflate, "gpu_inflate": a.gpu_inflate, "workers_per_gpu": a.workers_per_gpu, "esa_compression": a.esa_compression, "dual_soil_fraction": a.dual_soil_fraction,
+    n_rasters = 18
+    if a.lookups or a.conditions:
+        n_rasters = (len([x for x in a.lookups.split(",") if x]) if a.lookups and a.lookups != "all" else 9) * \
+            (1 if a.conditions in ("drained", "undrained") else 2)
+    res = {"size": size, "blocks": nb, "rasters_per_block": n_rasters, "strip_rows": a.strip_rows, "gpus": a.gpus, "pattern": a.pattern, "gpu_deflate": a.gpu_deflate, "gpu_inflate": a.gpu_inflate, "workers_per_gpu": a.workers_per_gpu, "esa_compression": a.esa_compression, "dual_soil_fraction": a.dual_soil_fraction,
            "world_build_seconds": round(build_s, 1), "modes": {}}
     for mode in a.modes.split(","):
         env = dict(os.environ)
@@ -122,11 +129,11 @@ def run_modes(a, wd, size, nb, build_s):
                 nbytes += sum(os.path.getsize(os.path.join(p, f)) for f in os.listdir(p))
         mt = re.search(r"worker seconds: (.*)", log)
         res["modes"][mode] = {"rc": out.returncode, "worker_seconds": mt.group(1) if mt else None, "blocks_done": done, "seconds": round(secs, 3),
-                              "cn_gpx_per_s": round(done * size * size * 18 / secs / 1e9, 3) if secs else None,
+                              "cn_gpx_per_s": round(done * size * size * n_rasters / secs / 1e9, 3) if secs else None,
                               "seconds_per_block": round(secs / done, 3) if done else None,
                               "seconds_after_startup": steady,
                               "steady_seconds_per_block": round(steady / done, 4) if done and steady else None,
-                              "steady_cn_gpx_per_s": round(done * size * size * 18 / steady / 1e9, 1) if steady else None,
+                              "steady_cn_gpx_per_s": round(done * size * size * n_rasters / steady / 1e9, 1) if steady else None,
                               "output_bytes": nbytes, "stderr_tail": out.stderr[-300:] if out.returncode else ""}
     print(json.dumps(res))
     for d in ("cn_rasters_drained", "cn_rasters_undrained", "logs"):
