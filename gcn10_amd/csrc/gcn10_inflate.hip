@@ -838,19 +838,40 @@ __device__ __forceinline__ uint32_t decode_batch(Shared &sh, Decoder &d, uint32_
         // ---- the chain: from bit 0 of the window, token by token.  One exit, no branches in the
         // body, one v_readlane per token: the loop is the serial core of the decoder.  The bytes the
         // tokens produce are summed afterwards (they are in the token words) ----
-        uint32_t k = 0, n_new = 0, src = 0, stop = 0, last_bits = 0;
-        const uint32_t room = (uint32_t)kBatch - n;
-        bool go = true;
-        while (go) {
-            const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)(k & 63u));
-            const uint32_t inf = (pk >> ((k >> 6) * 8u)) & 0xffu;
-            src = (uint32_t)lane == n_new ? k : src;    // (a stop token's entry lies beyond n_new: unused)
-            n_new += inf < 0x40u ? 1u : 0u;
-            last_bits = inf & 63u;
-            k += last_bits;
-            stop = inf >> 6;
-            go = (stop == 0u) & (n_new < room) & (k < 64u * (uint32_t)kCand);
-        }
+        // Written out, 17 instructions per token (the compiler's form of the same loop takes 24): the
+        // start bit of the it-th token goes to lane `it` with one v_writelane (lane select in M0: two
+        // different SGPR operands would break the constant-bus rule), and the three reasons to stop -- a
+        // stop token, the end of the window, a full batch -- are chained through two scalar selects.
+        const uint32_t room = (uint32_t)kBatch - n;        // 1..64: also keeps `it` within the 64 lanes
+        uint32_t k = 0, it = 0, inf, t0, t1, m0_saved;
+        uint32_t src = 0;
+        asm volatile("s_mov_b32 %[m0s], m0\n"
+                     "1:\n\t"
+                     "v_readlane_b32 %[t0], %[packed], %[k]\n\t"       // lane k mod 64
+                     "s_lshr_b32 %[t1], %[k], 3\n\t"
+                     "s_and_b32 %[t1], %[t1], 24\n\t"
+                     "s_mov_b32 m0, %[it]\n\t"
+                     "s_lshr_b32 %[t0], %[t0], %[t1]\n\t"
+                     "s_and_b32 %[inf], %[t0], 0xff\n\t"
+                     "v_writelane_b32 %[src], %[k], m0\n\t"            // src[lane it] = k
+                     "s_add_u32 %[it], %[it], 1\n\t"
+                     "s_and_b32 %[t0], %[inf], 63\n\t"
+                     "s_add_u32 %[k], %[k], %[t0]\n\t"
+                     "s_cmp_lt_u32 %[inf], 64\n\t"
+                     "s_cselect_b32 %[t0], %[k], 0x100\n\t"            // a stop token ends the walk
+                     "s_cmp_lt_u32 %[t0], 0x100\n\t"
+                     "s_cselect_b32 %[t0], %[it], %[room]\n\t"         // so does the end of the window
+                     "s_cmp_lt_u32 %[t0], %[room]\n\t"                 // ... and a full batch
+                     "s_cbranch_scc1 1b\n\t"
+                     "s_mov_b32 m0, %[m0s]"                              // (M0 is the compiler's: put it back)
+                     : [k] "+s"(k), [it] "+s"(it), [inf] "=&s"(inf), [t0] "=&s"(t0), [t1] "=&s"(t1), [src] "+v"(src),
+                       [m0s] "=&s"(m0_saved)
+                     : [packed] "v"(packed), [room] "s"(room)
+                     : "scc");
+        static_assert(kCand == 4, "the walk's window end is written as 0x100");
+        uint32_t stop = inf >> 6;
+        const uint32_t last_bits = inf & 63u;
+        uint32_t n_new = stop != 0u ? it - 1u : it;        // a stop token is not a token of the stream
         {
             const int sel = (int)((src & 63u) << 2);
             uint32_t mine = 0;
