@@ -998,9 +998,12 @@ int gcn10_run(const gcn10_run_options *opt)
         if ((r->cond_mask >> (k / 9)) & 1u && (r->table_mask >> (k % 9)) & 1u)
             r->sel[r->n_sel++] = k;
     r->null_sink = sink && strcmp(sink, "null") == 0;
-    /* 1024 rows: measured best end to end (768..1280 within noise; 1792 fills the GPU's workgroup
-     * slots in whole rounds and encodes 16-19 % faster per row, but the coarser hand-over between
-     * kernels, copy-back and file writes costs more than that: 0.173 vs 0.156 s per block) */
+    /* 768 rows: three tile rows of a 36000-px block are 423 tile positions, one round of the fused
+     * statistics pass's 512 workgroup slots (1024 rows: 564 positions, a full round and a ragged one).
+     * Round 2, 16 blocks, null sink: 0.0267 vs 0.0277-0.0297 s per block on patchy tiles, 0.0557 vs
+     * 0.0564-0.0573 on noisy ones (profiles/r02/strip_rows_ab.txt); 512 and 1280 are no better, and 1792
+     * (whole rounds again, 16-19 % faster per row at kernel level) loses end to end to the coarser
+     * hand-over between kernels, copy-back and file writes */
     r->strip_rows = r->cfg.strip_rows > 0 ? (r->cfg.strip_rows + TILE - 1) / TILE * TILE : DEFAULT_STRIP_ROWS;
     if (r->strip_rows > MAX_STRIP_ROWS)     /* a strip's compressed-tile arena must stay below 4 GiB (32-bit offsets) */
         r->strip_rows = MAX_STRIP_ROWS;

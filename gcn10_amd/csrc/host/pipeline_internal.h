@@ -12,7 +12,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-enum { TILE = 256, MAX_NBUF = 4, DEFAULT_NBUF = 3, DEFAULT_STRIP_ROWS = 1024, MAX_STRIP_ROWS = 4096 };
+enum { TILE = 256, MAX_NBUF = 4, DEFAULT_NBUF = 3, DEFAULT_STRIP_ROWS = 768, MAX_STRIP_ROWS = 4096 };
 
 struct run;
 

@@ -91,7 +91,7 @@ typedef struct gcn10_config {
     /* optional extensions (absent = default) */
     int gpus;               /* "gpus": number of GPUs to use, 0 = all visible      */
     int workers_per_gpu;    /* "workers_per_gpu": block workers per GPU, 0 = default 2 */
-    int strip_rows;         /* "strip_rows": rows per staging strip, 0 = default 1024 */
+    int strip_rows;         /* "strip_rows": rows per staging strip, 0 = default 768 */
     int io_threads;         /* "io_threads": tile compression threads, 0 = auto    */
     int deflate_level;      /* "deflate_level": zlib level 1..9, 0 = zlib default 6 */
     char *esa_tile_dir;     /* "esa_tile_dir": local mirror of /vsicurl/ VRT sources */
