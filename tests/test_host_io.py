@@ -417,3 +417,26 @@ def test_tiff_writer_gathered_tile_writes(tmp_path):
     w = L.gcn10_tiff_create(p.encode(), 300, 300, gt, None, err, 512)
     assert L.gcn10_tiff_put_tiles(w, 1, (C.c_int * 1)(2), (C.c_int * 1)(0), ptrs, sizes) == -1
     assert L.gcn10_tiff_finish(w, err, 512) != 0
+
+
+def test_config_lookups_and_conditions_keys(tmp_path):
+    """Round-2 keys of the config file (BASELINE config 3, "single lookup"): names in the reference's
+    loop order p,f,g x i,ii,iii (src/cn.c:146-147) -> bit k = hc*3 + arc; drained = bit 0 (src/cn.c:145)."""
+    base = "hysogs_data_path=a\nesa_data_path=b\nblocks_shp_path=c\nlookup_table_path=d\nlog_dir=e\n"
+    p = tmp_path / "c.txt"
+    p.write_text(base)
+    cfg = host.parse_config(str(p))
+    assert cfg["table_mask"] == 0x1FF and cfg["cond_mask"] == 3            # absent = all 18 rasters
+    p.write_text(base + "lookups = p_i, g_iii\nconditions=undrained\n")
+    cfg = host.parse_config(str(p))
+    assert cfg["table_mask"] == (1 << 0) | (1 << 8) and cfg["cond_mask"] == 2
+    p.write_text(base + "lookups=all\nconditions=drained,undrained\n")
+    cfg = host.parse_config(str(p))
+    assert cfg["table_mask"] == 0x1FF and cfg["cond_mask"] == 3
+    p.write_text(base + "lookups=g_ii\nlookups=f_i\n")                       # a repeated key: the last one wins
+    assert host.parse_config(str(p))["table_mask"] == 1 << 3
+    for bad in ("lookups=g_iv\n", "lookups=\n", "conditions=wet\n", "lookups=g-ii\n"):
+        p.write_text(base + bad)
+        with pytest.raises(host.HostError) as e:
+            host.parse_config(str(p))
+        assert "bad value for" in str(e.value)
