@@ -311,6 +311,13 @@ def main(argv=None):
     outs = [None] * 18
     out_bufs = []
     placement = None
+    # (A/B switch: allocating the 17 extra rasters of the config4 leg BEFORE the calibration's candidates put
+    # every candidate in a slow place in both processes that tried it -- 0.484 ms against 0.438-0.465 ms,
+    # profiles/r02/bench_alloc_order_ab.txt -- so they are allocated after it)
+    extra_first = os.environ.get("GCN10_BENCH_EXTRA_FIRST", "0") == "1"
+    extra = []
+    if extra_first and world == 1 and not args.no_also and args.workload == "config2" and not preresampled:
+        extra = [eng.alloc(size * size) for _ in range(17)]
     tune = (n_out == 1 and not preresampled and not args.no_tune and not args.strip_rows
             and hasattr(eng, "tune_single_raster"))
     for r in range(18):
@@ -360,8 +367,9 @@ def main(argv=None):
                 out_bufs.append(b)
                 outs[r] = b.ptr
     out0 = next(p for p in outs if p)
-    # the extra config4 measurement writes 18 rasters: allocate them now, long before they are timed
-    extra = [eng.alloc(npix) for _ in range(17)] if want_also else []
+    if want_also and not extra:
+        # the extra config4 measurement writes 18 rasters: allocate the other 17 now, long before they are timed
+        extra = [eng.alloc(npix) for _ in range(17)]
     d_fine = None
     if preresampled:
         d_fine = eng.alloc(npix)
