@@ -166,7 +166,7 @@ __device__ __forceinline__ int next_set(const unsigned long long (&m)[4], int x)
 // and bit x of `start` is set.  Every mask of the tile must have been computed before.
 // Returns the number of tokens of the row.
 __device__ __forceinline__ uint32_t tokenise_row(uint8_t *tile, int t, const RowMasks &m, uint32_t *lit_hist,
-                                                 uint32_t *dist_hist, unsigned long long (&start)[4])
+                                                 uint32_t *dist_hist, unsigned long long (&start)[4], bool diag_no_lit)
 {
     uint8_t *row = tile + t * kRowStride;
     int x = 0;
@@ -175,6 +175,8 @@ __device__ __forceinline__ uint32_t tokenise_row(uint8_t *tile, int t, const Row
     while (x < kTile) {
         const int cand = next_candidate(m, x);
         n_tokens += (uint32_t)(cand - x);
+        if (diag_no_lit)
+            x = cand;
         for (; x < cand; x++)
             atomicAdd(&lit_hist[row[x]], 1u);
         if (x >= kTile)
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(kTile) void fused_stats_kernel(const FusedJob job)
         }
     }
     unsigned long long start[4];
-    const uint32_t my_tokens = tokenise_row(sh.tile, t, m, sh.a.lit_hist, sh.a.dist_hist, start);
+    const uint32_t my_tokens = tokenise_row(sh.tile, t, m, sh.a.lit_hist, sh.a.dist_hist, start, (job.diag & 8u) != 0u);
     // rows back to back: where this row's tokens go
     {
         uint32_t incl = my_tokens;
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(kTile) void fused_stats_kernel(const FusedJob job)
             at += sh.a.row_base[w];
         uint16_t *out = job.tok + (size_t)tix * kTokStride;
         const uint8_t *row = sh.tile + t * kRowStride;
-        int x = 0;
+        int x = (job.diag & 16u) ? kTile : 0;       // (timing experiment: no token write-out)
         while (x < kTile) {
             const int p = next_set(start, x);
             for (; x < p; x++)

@@ -1475,7 +1475,7 @@ int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value)
         ctx->xcd_slabs = value;
     else if (!strcmp(name, "deflate_wave_codes") && (value == 0 || value == 1))
         ctx->deflate_wave_codes = value;
-    else if (!strcmp(name, "fused_diag") && value >= 0 && value < 8)
+    else if (!strcmp(name, "fused_diag") && value >= 0 && value < 32)
         ctx->fused_diag = value;
     else if (!strcmp(name, "inflate_diag") && value >= 0 && value < 4)
         ctx->inflate_diag = value;
