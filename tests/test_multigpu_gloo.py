@@ -178,3 +178,30 @@ def test_bench_strong_scaling_splits_one_block_into_row_bands():
     assert bands[0][0] == 0 and bands[0][1] == bands[1][0] and bands[1][1] == 2050 and bands[0][1] % 16 == 0
     want = 2050 * 2050 * 1 * 3 / (rec["ms_per_step"] * 3e-3) / 1e9          # ONE block over both GPUs
     assert abs(rec["value"] - want) / want < 1e-3
+
+
+def test_bench_line_has_the_contract_fields_and_cpu_baseline_schema():
+    """The one JSON line: every field of the driver's contract, roofline / cpu_baseline objects, and the
+    cpu_baseline legs (P = 1, the box share, all physical cores, the fused best-CPU pass) on a small width."""
+    out = _bench(["--steps", "2", "--warmup", "1", "--size", "2048"], extra_env={"GCN10_CPU_BASELINE_PROCS": "2"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "per_rank"):
+        assert k in rec, k
+    assert rec["metric"] == "CN Gpixels/sec" and rec["unit"] == "Gpx/s" and rec["dtype"] == "u8"
+    assert rec["higher_is_better"] is True and rec["vs_baseline"] is None and "workload" in rec["config"]
+    ro = rec["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "algorithmic_bytes_per_launch",
+              "avg_launch_ms", "copy_ceiling", "frac_of_copy", "placement"):
+        assert k in ro, k
+    assert ro["bound"] == "hbm" and ro["peak"] == 8000.0 and ro["unit"] == "GB/s"
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
+    cb = rec["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample", "runs", "best_cpu", "host_physical_cores"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["unit"] == "CN Gpx/s" and cb["value"] > 0
+    labels = [r["label"] for r in cb["runs"]]
+    assert labels[0] == "P=1" and any("share" in l for l in labels)
+    assert cb["value"] == max(r["gpx_per_s"] for r in cb["runs"]) and cb["cores"] in [r["procs"] for r in cb["runs"]]
+    assert cb["best_cpu"]["gpx_per_s"] > 0
