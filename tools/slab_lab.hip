@@ -77,7 +77,54 @@ __global__ __launch_bounds__(kThreads) void order_copy(const u32x4 *in, u32x4 *o
     }
 }
 
+// Every workgroup streams its OWN contiguous band of the buffer (band = ntrips / gridDim trips), trip by trip:
+// 2048 or 4096 sequential streams instead of 8 windows that all workgroups of an XCD share.  (What a kernel
+// that gives each workgroup the raster rows of one soil row would do to the memory system.)
+__global__ __launch_bounds__(kThreads) void band_copy(const u32x4 *in, u32x4 *out, uint32_t nvec, uint32_t ntrips,
+                                                      uint32_t xcd_major)
+{
+    const uint32_t nb = gridDim.x;
+    // xcd_major: consecutive bands go to the workgroups of one XCD (b & 7 = XCD), else round-robin over XCDs
+    const uint32_t b = xcd_major ? (blockIdx.x & 7u) * (nb / 8u) + (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t per = (ntrips + nb - 1u) / nb;
+    const uint32_t lo = b * per;
+    const uint32_t hi = lo + per < ntrips ? lo + per : ntrips;
+    for (uint32_t trip = lo; trip < hi; trip++) {
+        u32x4 v[2];
+        uint32_t idx[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            idx[u] = (trip * 2u + u) * (uint32_t)kThreads + threadIdx.x;
+            v[u] = __builtin_nontemporal_load(in + (idx[u] < nvec ? idx[u] : 0u));
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            if (idx[u] < nvec)
+                __builtin_nontemporal_store(v[u], out + idx[u]);
+    }
+}
+
 static hipEvent_t e0[5], e1[5];
+
+static float time_band(const void *src, void *dst, size_t bytes, uint32_t xcd_major, int bpc)
+{
+    uint32_t nvec = (uint32_t)(bytes / 16);
+    uint32_t ntrips = (nvec + 2 * kThreads - 1) / (2 * kThreads);
+    uint32_t grid = 256 * bpc;
+    const u32x4 *in = (const u32x4 *)src;
+    u32x4 *out = (u32x4 *)dst;
+    void *args[] = { &in, &out, &nvec, &ntrips, &xcd_major };
+    hipLaunchKernelGGL(band_copy, dim3(grid), dim3(kThreads), 0, 0, in, out, nvec, ntrips, xcd_major);
+    for (int k = 0; k < 5; k++)
+        CHECK(hipExtLaunchKernel(reinterpret_cast<const void *>(band_copy), dim3(grid), dim3(kThreads), args, 0, 0,
+                                 e0[k], e1[k], 0));
+    CHECK(hipDeviceSynchronize());
+    float ms[5];
+    for (int k = 0; k < 5; k++)
+        CHECK(hipEventElapsedTime(&ms[k], e0[k], e1[k]));
+    std::sort(ms, ms + 5);
+    return ms[2];
+}
 
 static float time_order(const void *src, void *dst, size_t bytes, uint32_t mult, uint32_t skew, uint32_t rev, int bpc)
 {
@@ -190,6 +237,21 @@ int main(int argc, char **argv)
                 float best = 1e30f;
                 for (int rnd = 0; rnd < 2; rnd++)
                     best = std::min(best, time_copy(arena, arena + first + (size_t)d * MiB, bytes, np.plan, bpc));
+                printf("%s%.4f", d ? ", " : "", best);
+            }
+            printf("]}\n");
+            fflush(stdout);
+        }
+    // one band per workgroup
+    for (int bpc = 4; bpc <= 16; bpc *= 2)
+        for (uint32_t xm = 0; xm < 2; xm++) {
+            printf("{\"memory\": \"%s\", \"blocks_per_cu\": %d, \"plan\": \"one contiguous band per workgroup, %s\", "
+                   "\"ms_by_D_minus_S_MiB\": [", contiguous ? "contiguous" : "hipMalloc", bpc,
+                   xm ? "neighbouring bands on one XCD" : "bands dealt round-robin over the XCDs");
+            for (int d = 0; d < 4; d++) {
+                float best = 1e30f;
+                for (int rnd = 0; rnd < 2; rnd++)
+                    best = std::min(best, time_band(arena, arena + first + (size_t)d * MiB, bytes, xm, bpc));
                 printf("%s%.4f", d ? ", " : "", best);
             }
             printf("]}\n");
