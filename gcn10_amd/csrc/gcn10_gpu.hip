@@ -75,6 +75,10 @@ struct StripParams {
     uint32_t table_mask;
     uint32_t single_k;      // table index for the single-table variant
     uint32_t xcd_slabs;     // 1: each XCD streams a contiguous eighth of the strip
+    // compact soil words (one dword per 16-px column group, see expand_x_codes); hx4 = null: not in use
+    const uint32_t *hx4;
+    const uint32_t *hx4_complex;    // device flag: nonzero = some group of the tile has no compact form
+    uint32_t hx4_stride;            // dwords per soil row
 };
 
 // soil code byte: low nibble = plane for "drained", high nibble = "undrained".
@@ -246,7 +250,7 @@ struct Trip {
     uint32_t i0[ILP];
 };
 
-template <int ILP, bool NT>
+template <int ILP, bool NT, bool HX4>
 __device__ __forceinline__ void issue_trip(const StripParams &p, uint32_t trip, uint32_t lane_off,
                                            uint32_t wave_off, Trip<ILP> &tr)
 {
@@ -277,6 +281,11 @@ __device__ __forceinline__ void issue_trip(const StripParams &p, uint32_t trip, 
 #if defined(GCN10_DIAG) && (GCN10_DIAG == 2 || GCN10_DIAG == 3)
         tr.c16[u] = u32x4{ row, xl, 0u, 0u } & 0x11111111u;    // timing-only build: no soil load
 #else
+        if (HX4) {
+            // W % 16 == 0: the lane's 16 pixels are one column group; its soil codes are one dword
+            tr.c16[u] = u32x4{ p.hx4[(size_t)row * p.hx4_stride + (xl >> 4)], 0u, 0u, 0u };
+            continue;
+        }
         const uint8_t *pa = p.hx + (size_t)row * p.hx_stride + xl;
         u32x4 a = load16_any(pa);
         if (p.W & 15u) {
@@ -301,13 +310,30 @@ __device__ __forceinline__ void issue_trip(const StripParams &p, uint32_t trip, 
 }
 
 // Table gathers and stores of one trip.
-template <int KIND, int COND_MASK, int ILP, bool NT>
+// Soil code bytes of a lane's 16 pixels from the compact word {code a, code b, split, -}: pixels [0, split)
+// have code a, the rest code b.
+__device__ __forceinline__ u32x4 expand_soil_word(uint32_t w)
+{
+    const uint32_t a = (w & 0xffu) * 0x01010101u, b = ((w >> 8) & 0xffu) * 0x01010101u;
+    const int32_t split = (int32_t)((w >> 16) & 0xffu);
+    u32x4 cd;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int32_t m = split - 4 * j;        // bytes of dword j that hold code a
+        const uint32_t mask = m >= 4 ? 0xffffffffu : (m <= 0 ? 0u : (1u << (8 * m)) - 1u);
+        cd[j] = (a & mask) | (b & ~mask);
+    }
+    return cd;
+}
+
+template <int KIND, int COND_MASK, int ILP, bool NT, bool HX4>
 __device__ __forceinline__ void finish_trip(const StripParams &p, const uint8_t *lut, uint32_t tmask,
                                             const Trip<ILP> &tr)
 {
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
         const bool live = tr.i0[u] < p.nvec16;
+        const u32x4 c16 = HX4 ? expand_soil_word(tr.c16[u][0]) : tr.c16[u];
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             if (!(COND_MASK & (1 << c)))
@@ -317,7 +343,7 @@ __device__ __forceinline__ void finish_trip(const StripParams &p, const uint8_t 
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint32_t e = tr.e16[u][j];
-                    const uint32_t cd = tr.c16[u][j];
+                    const uint32_t cd = c16[j];
                     u32x4 r4[4];
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
@@ -345,12 +371,12 @@ __device__ __forceinline__ void finish_trip(const StripParams &p, const uint8_t 
             else {
                 u32x4 v;
 #if defined(GCN10_DIAG) && (GCN10_DIAG == 1 || GCN10_DIAG == 3)
-                v = tr.e16[u] ^ tr.c16[u];          // timing-only build: no table lookup
+                v = tr.e16[u] ^ c16;          // timing-only build: no table lookup
 #else
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint32_t e = tr.e16[u][j];
-                    const uint32_t cd = tr.c16[u][j];
+                    const uint32_t cd = c16[j];
                     uint32_t w = 0;
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
@@ -365,6 +391,43 @@ __device__ __forceinline__ void finish_trip(const StripParams &p, const uint8_t 
                 if (live)
                     store16<NT>(p.out[c * 9 + p.single_k] + tr.i0[u], v);
             }
+        }
+    }
+}
+
+// The trip loop of cn_strip_kernel (HX4: soil codes from the compact words).
+template <int KIND, int COND_MASK, int ILP, bool NT, bool PF, bool HX4>
+__device__ __forceinline__ void strip_loop(const StripParams &p, const uint8_t *lut, uint32_t tmask,
+                                           uint32_t lane_off, uint32_t wave_off)
+{
+    // p.nchunks counts trips (groups of ILP chunks of 4096 px) here
+    uint32_t step, end;
+    uint32_t trip = first_chunk(p.nchunks, step, end, p.xcd_slabs != 0);
+    if (!PF) {
+        for (; trip < end; trip += step) {
+            Trip<ILP> tr;
+            issue_trip<ILP, NT, HX4>(p, trip, lane_off, wave_off, tr);
+            finish_trip<KIND, COND_MASK, ILP, NT, HX4>(p, lut, tmask, tr);
+        }
+    }
+    else if (trip < end) {
+        Trip<ILP> ta, tb;       // used alternately: a copy would wait for the loads it copies
+        issue_trip<ILP, NT, HX4>(p, trip, lane_off, wave_off, ta);
+        for (;;) {
+            trip += step;
+            if (trip >= end) {
+                finish_trip<KIND, COND_MASK, ILP, NT, HX4>(p, lut, tmask, ta);
+                break;
+            }
+            issue_trip<ILP, NT, HX4>(p, trip, lane_off, wave_off, tb);
+            finish_trip<KIND, COND_MASK, ILP, NT, HX4>(p, lut, tmask, ta);
+            trip += step;
+            if (trip >= end) {
+                finish_trip<KIND, COND_MASK, ILP, NT, HX4>(p, lut, tmask, tb);
+                break;
+            }
+            issue_trip<ILP, NT, HX4>(p, trip, lane_off, wave_off, ta);
+            finish_trip<KIND, COND_MASK, ILP, NT, HX4>(p, lut, tmask, tb);
         }
     }
 }
@@ -393,36 +456,12 @@ __global__ __launch_bounds__(kThreads) void cn_strip_kernel(const StripParams p)
     const uint32_t wave_off = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * kWavePx;
     const uint32_t tmask = ALL_TABLES ? 0x1ffu : p.table_mask;
 
-    // p.nchunks counts trips (groups of ILP chunks of 4096 px) here
-    uint32_t step, end;
-    uint32_t trip = first_chunk(p.nchunks, step, end, p.xcd_slabs != 0);
-    if (!PF) {
-        for (; trip < end; trip += step) {
-            Trip<ILP> tr;
-            issue_trip<ILP, NT>(p, trip, lane_off, wave_off, tr);
-            finish_trip<KIND, COND_MASK, ILP, NT>(p, lut, tmask, tr);
-        }
-    }
-    else if (trip < end) {
-        Trip<ILP> ta, tb;       // used alternately: a copy would wait for the loads it copies
-        issue_trip<ILP, NT>(p, trip, lane_off, wave_off, ta);
-        for (;;) {
-            trip += step;
-            if (trip >= end) {
-                finish_trip<KIND, COND_MASK, ILP, NT>(p, lut, tmask, ta);
-                break;
-            }
-            issue_trip<ILP, NT>(p, trip, lane_off, wave_off, tb);
-            finish_trip<KIND, COND_MASK, ILP, NT>(p, lut, tmask, ta);
-            trip += step;
-            if (trip >= end) {
-                finish_trip<KIND, COND_MASK, ILP, NT>(p, lut, tmask, tb);
-                break;
-            }
-            issue_trip<ILP, NT>(p, trip, lane_off, wave_off, ta);
-            finish_trip<KIND, COND_MASK, ILP, NT>(p, lut, tmask, tb);
-        }
-    }
+    // compact soil words when the host offers them and no column group of this tile is complex
+    // (wave-uniform: the flag comes through the scalar cache)
+    if (p.hx4 && scalar_load_i32(reinterpret_cast<const int32_t *>(p.hx4_complex), 0u) == 0)
+        strip_loop<KIND, COND_MASK, ILP, NT, PF, true>(p, lut, tmask, lane_off, wave_off);
+    else
+        strip_loop<KIND, COND_MASK, ILP, NT, PF, false>(p, lut, tmask, lane_off, wave_off);
 
     // the last npix % 16 pixels, one per thread
     if (blockIdx.x == 0 && threadIdx.x < p.npix - p.nvec16) {
@@ -507,6 +546,16 @@ __global__ __launch_bounds__(kThreads) void cn_strip_bytes(const StripParams p,
 // ------------------------------------------------------------------------
 // x-expansion of the coarse soil window (the x half of src/cn.c:218-232):
 // hx[r][x] = soil_code(coarse[r][ci[x]]) for every coarse row r.
+//
+// Next to the bytes, one COMPACT WORD per 16-px column group and coarse row:
+// hx4[r][g] = code a | code b << 8 | split << 16, meaning pixels [0, split)
+// of the group have code a and the rest code b.  At the usual ratio (25 fine
+// columns per coarse cell) every group has that form, and the strip kernels
+// then load one dword per lane instead of 16 bytes (the soil stream costs the
+// single-raster kernel 5 % with bytes, 1-2 % with words: DESIGN.md section 5).
+// A group that has no such form (three cells under 16 columns, a map that is
+// not monotone) gets split = 0xff and raises *complex; the strip kernels read
+// that flag and use the bytes for the whole tile.
 // ------------------------------------------------------------------------
 constexpr uint32_t kExpandRows = 2;     // coarse rows per thread of expand_x_codes
 
@@ -514,7 +563,8 @@ template <bool VEC>
 __global__ __launch_bounds__(kThreads) void expand_x_codes(const uint8_t *coarse,
                                                            uint32_t hsx, uint32_t hsy,
                                                            const int32_t *ci, uint32_t W,
-                                                           uint8_t *hx, uint32_t hx_stride)
+                                                           uint8_t *hx, uint32_t hx_stride,
+                                                           uint32_t *hx4, uint32_t *complex)
 {
     // one thread = 16 consecutive fine columns of kExpandRows coarse rows: the 16 column indices are
     // loaded once (dwordx4 when ci is 16-byte aligned) and clamped once, then per row 16 byte gathers
@@ -544,12 +594,24 @@ __global__ __launch_bounds__(kThreads) void expand_x_codes(const uint8_t *coarse
             cx[q] = c == 0xffffffffu ? c : (c < hsx ? c : hsx - 1u);
         }
     }
-    // the column map is monotone, and at the usual ratio (25 fine columns per coarse cell) 16 consecutive
-    // columns see at most two coarse cells: two byte loads and 16 selects instead of 16 byte gathers
-    // (the kernel is bound by the number of load instructions, not by bytes)
+    // at the usual ratio (25 fine columns per coarse cell) 16 consecutive columns see at most two coarse
+    // cells, the first column's and the last one's: two byte loads and 16 selects instead of 16 byte
+    // gathers (the kernel is bound by the number of load instructions, not by bytes)
     const uint32_t c_lo = cx[0], c_hi = cx[15];
-    const bool two = c_lo != 0xffffffffu && c_hi != 0xffffffffu && c_hi - c_lo <= 1u;
     const uint32_t r1 = r0 + kExpandRows < hsy ? r0 + kExpandRows : hsy;
+    // compact form: a run of c_lo followed by a run of c_hi (also: padding only, right of the raster)
+    uint32_t split = 0;
+    bool compact = true, in_set = true;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const bool lo = cx[q] == c_lo;
+        in_set = in_set && (lo || cx[q] == c_hi);
+        compact = compact && (lo ? split == (uint32_t)q : cx[q] == c_hi);
+        split += lo && split == (uint32_t)q ? 1u : 0u;
+    }
+    const bool two = c_lo != 0xffffffffu && c_hi != 0xffffffffu && in_set;
+    if (hx4 && x < W && !compact && *reinterpret_cast<volatile uint32_t *>(complex) == 0u)
+        atomicOr(complex, 1u);
     for (uint32_t r = r0; r < r1; r++) {
         const uint8_t *row = coarse + (size_t)r * hsx;
         u32x4 o;
@@ -578,6 +640,9 @@ __global__ __launch_bounds__(kThreads) void expand_x_codes(const uint8_t *coarse
             }
         }
         *reinterpret_cast<u32x4 *>(hx + (size_t)r * hx_stride + x) = o;
+        if (hx4)
+            hx4[(size_t)r * (hx_stride / 16u) + x / 16u] =
+                compact ? (o[0] & 0xffu) | ((o[3] >> 24) << 8) | (split << 16) : 0x00ff0000u;
     }
 }
 
@@ -1436,21 +1501,33 @@ int gcn10_gpu_prepare_tile(gcn10_gpu_ctx *ctx, const uint8_t *coarse, int hsx, i
         if (ctx->d_hx_alloc)
             HIP_TRY(hipFree(ctx->d_hx_alloc));
         ctx->d_hx_alloc = ctx->d_hx = nullptr;
+        ctx->d_hx4 = ctx->d_hx4_complex = nullptr;
+        ctx->hx4_ready = false;
         ctx->hx_capacity = 0;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_hx_alloc), need + 16));
+        // behind the code bytes: the compact words (a quarter of the bytes) and their "complex" flag
+        const size_t need16 = (need + 15) & ~(size_t)15;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_hx_alloc), 16 + need16 + need16 / 4 + 16));
         ctx->d_hx = ctx->d_hx_alloc + 16;
+        ctx->d_hx4 = reinterpret_cast<uint32_t *>(ctx->d_hx + need16);
+        ctx->d_hx4_complex = reinterpret_cast<uint32_t *>(ctx->d_hx + need16 + need16 / 4);
         ctx->hx_capacity = need;
     }
+    uint32_t *hx4 = ctx->compact_soil ? ctx->d_hx4 : nullptr;
+    ctx->hx4_ready = hx4 != nullptr;
+    if (hx4)
+        HIP_TRY(hipMemsetAsync(ctx->d_hx4_complex, 0, 4, as_stream(ctx, stream)));
     ctx->hx_stride = stride;
     ctx->hx_W = (uint32_t)W;
     ctx->hx_rows = (uint32_t)hsy;
     dim3 grid((stride / 16 + kThreads - 1) / kThreads, ((uint32_t)hsy + kExpandRows - 1) / kExpandRows);
     if (aligned16(ci))
         hipLaunchKernelGGL(expand_x_codes<true>, grid, dim3(kThreads), 0, as_stream(ctx, stream),
-                           coarse, (uint32_t)hsx, (uint32_t)hsy, ci, (uint32_t)W, ctx->d_hx, stride);
+                           coarse, (uint32_t)hsx, (uint32_t)hsy, ci, (uint32_t)W, ctx->d_hx, stride, hx4,
+                           ctx->d_hx4_complex);
     else
         hipLaunchKernelGGL(expand_x_codes<false>, grid, dim3(kThreads), 0, as_stream(ctx, stream),
-                           coarse, (uint32_t)hsx, (uint32_t)hsy, ci, (uint32_t)W, ctx->d_hx, stride);
+                           coarse, (uint32_t)hsx, (uint32_t)hsy, ci, (uint32_t)W, ctx->d_hx, stride, hx4,
+                           ctx->d_hx4_complex);
     HIP_TRY(hipGetLastError());
     return GCN10_OK;
 }
@@ -1509,6 +1586,12 @@ int gcn10_gpu_cn_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, int rows,
 
     p.xcd_slabs = (uint32_t)ctx->xcd_slabs;
     p.nvec16 = p.npix & ~15u;
+    if (ctx->hx4_ready && ctx->compact_soil && (p.W & 15u) == 0u) {
+        // rows are 16-byte aligned: a lane's 16 pixels are one column group of the compact soil words
+        p.hx4 = ctx->d_hx4;
+        p.hx4_complex = ctx->d_hx4_complex;
+        p.hx4_stride = ctx->hx_stride / 16u;
+    }
     // the vector kernel wants a wave's 1024-px span to cross at most one row end
     if (p.npix < 16u || p.W < kMinVectorW)
         all_aligned = false;
@@ -1595,6 +1678,7 @@ int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value)
         ctx->nontemporal = fresh.nontemporal;
         ctx->xcd_slabs = fresh.xcd_slabs;
         ctx->prefetch = fresh.prefetch;
+        ctx->compact_soil = fresh.compact_soil;
         ctx->deflate_wave_codes = fresh.deflate_wave_codes;
         ctx->fused_diag = fresh.fused_diag;
         ctx->inflate_diag = fresh.inflate_diag;
@@ -1620,6 +1704,8 @@ int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value)
         ctx->inflate_diag = value;
     else if (!strcmp(name, "prefetch") && (value == -1 || value == 0 || value == 1))
         ctx->prefetch = value;
+    else if (!strcmp(name, "compact_soil") && (value == 0 || value == 1))
+        ctx->compact_soil = value;      // strips launched from now on; 1 needs a gcn10_gpu_prepare_tile made with it on
     else
         return fail(GCN10_E_INVAL, "gcn10_gpu_set_option: unknown option or bad value: %s=%d", name, value);
     return GCN10_OK;
@@ -1760,6 +1846,20 @@ int gcn10_gpu_tune_single_raster(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, 
                  n_pos, step, sizeof shapes / sizeof shapes[0], best, worst, best_pos, best_shape.xcd, best_shape.bpc,
                  best_shape.ilp, best_shape.pf);
     return GCN10_OK;
+}
+
+int gcn10_gpu_soil_words_state(gcn10_gpu_ctx *ctx, gcn10_stream_t stream)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (!ctx->hx4_ready || !ctx->d_hx4_complex)
+        return 0;
+    uint32_t flag = 0;
+    hipStream_t s = as_stream(ctx, stream);
+    HIP_TRY(hipMemcpyAsync(&flag, ctx->d_hx4_complex, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return flag ? 2 : 1;
 }
 
 const char *gcn10_gpu_last_kernel_name(gcn10_gpu_ctx *ctx)

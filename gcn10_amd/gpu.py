@@ -42,7 +42,7 @@ ABI_SYMBOLS = (
     "gcn10_gpu_pci_bus_id", "gcn10_gpu_deflate_fused_strip",
     "gcn10_gpu_deflate_fused_available",
     "gcn10_gpu_inflate_tiles", "gcn10_gpu_stream_copy", "gcn10_gpu_tune_single_raster",
-    "gcn10_gpu_malloc_contiguous", "gcn10_gpu_malloc_spread",
+    "gcn10_gpu_malloc_contiguous", "gcn10_gpu_malloc_spread", "gcn10_gpu_soil_words_state",
 )
 
 
@@ -107,6 +107,7 @@ def lib():
             "gcn10_gpu_tune_single_raster": (i, [vp, vp, i, i, vp, u, u, vp, sz, sz, C.POINTER(vp),
                                                  C.POINTER(C.c_float), C.c_char_p, sz, vp]),
             "gcn10_gpu_pci_bus_id": (i, [i, C.c_char_p, sz]),
+            "gcn10_gpu_soil_words_state": (i, [vp, vp]),
             "gcn10_gpu_deflate_fused_strip": (i, [vp, vp, i, i, vp, u, u, vp, sz, vp, vp, vp]),
             "gcn10_gpu_deflate_fused_available": (i, [vp]),
             "gcn10_gpu_inflate_tiles": (i, [vp, vp, vp, i, u, vp, sz, vp, vp]),
@@ -311,6 +312,14 @@ class Engine:
     def stream_copy(self, src, dst, nbytes: int, stream=None):
         """Plain 1R:1W copy with the strip kernel's launch shape (the same-run streaming ceiling)."""
         self._chk(lib().gcn10_gpu_stream_copy(self._ctx, src, dst, int(nbytes), stream), "gcn10_gpu_stream_copy")
+
+    def soil_words_state(self, stream=None) -> int:
+        """0 = code bytes (option off), 1 = compact words, 2 = code bytes (a column group of the prepared tile
+        spans more than two soil cells); see include/gcn10_gpu.h."""
+        rc = lib().gcn10_gpu_soil_words_state(self._ctx, stream)
+        if rc < 0:
+            self._chk(rc, "gcn10_gpu_soil_words_state")
+        return rc
 
     def last_kernel_name(self) -> str:
         return lib().gcn10_gpu_last_kernel_name(self._ctx).decode()

@@ -161,6 +161,10 @@ int gcn10_gpu_calculate_cn(gcn10_gpu_ctx *ctx, const uint8_t *esa,
  * gcn10_gpu_prepare_tile: once per block.  Expands the coarse soil window
  * along x only (one row of W bytes per coarse row, kept in a device workspace
  * that stays L2 / Infinity-Cache resident) -- the x half of src/cn.c:218-232.
+ * Next to the bytes it writes one compact word per 16-pixel column group and
+ * coarse row (two codes and the position where the second begins); strips
+ * whose width is a multiple of 16 read those instead of the bytes when every
+ * group of the tile has that form (gcn10_gpu_soil_words_state).
  *
  * gcn10_gpu_cn_strip: any number of times per block, one row strip each
  * (rows y0 .. y0+rows of the block; `esa` and every out[] pointer address the
@@ -250,7 +254,8 @@ int gcn10_gpu_inflate_tiles(gcn10_gpu_ctx *ctx, const uint8_t *comp_dev,
 
 /* Launch-shape knobs of the strip kernels, for tuning runs; results never
  * depend on them.  Names: "grid_blocks_per_cu" (1..64), "ilp16" (0 = by raster count | 1 | 2),
- * "ilp1" (1|2|4), "nontemporal" (0|1), "xcd_slabs" (0|1), "prefetch" (software pipeline of the strip kernels: -1 = default = on | 0 | 1), "deflate_wave_codes" (0|1: code
+ * "ilp1" (1|2|4), "nontemporal" (0|1), "xcd_slabs" (0|1), "prefetch" (software pipeline of the strip kernels: -1 = default = on | 0 | 1), "compact_soil" (0|1: gcn10_gpu_prepare_tile writes,
+ * and strips of 16-byte aligned rows read, the compact soil words; default 1), "deflate_wave_codes" (0|1: code
  * construction of the tile encoder by one thread or one wave per tile), "fused_diag" (timing
  * experiments on the fused encoder; nonzero values produce invalid streams), "defaults" (value
  * ignored: every knob back to its built-in default). */
@@ -288,6 +293,13 @@ int gcn10_gpu_tune_single_raster(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, 
                                  uint8_t *arena, size_t arena_bytes, size_t step,
                                  uint8_t **best_out, float *best_ms, char *report, size_t report_cap,
                                  gcn10_stream_t stream);
+
+/* What the strips of the tile last prepared on this context read their soil codes from (synchronises
+ * `stream`, on which gcn10_gpu_prepare_tile ran): 0 = code bytes (compact words switched off with
+ * gcn10_gpu_set_option("compact_soil", 0)), 1 = compact words -- one dword per 16-pixel column group, used by
+ * strips whose width is a multiple of 16 --, 2 = code bytes because some column group of this tile spans
+ * more than two soil cells.  <0 on error.  A diagnostic: nothing needs to call it. */
+int gcn10_gpu_soil_words_state(gcn10_gpu_ctx *ctx, gcn10_stream_t stream);
 
 /* Name of the variant of the strip kernel the last cn_strip call launched
  * (for profiles and bench records). */

@@ -158,6 +158,75 @@ def test_subsets_vector_kernels(eng9, tables, cond_mask, table_mask, W):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("W,H,hsx,hsy,state", [
+    (1040, 40, 50, 5, 1),          # narrowest width of the vector kernels; ~21 columns per soil cell
+    (2048, 33, 82, 7, 1),
+    (4112, 21, 170, 3, 1),
+    (36000, 9, 1440, 2, 1),        # the BASELINE ratio (25 columns per cell)
+    (2048, 30, 128, 4, 1),         # exactly 16 columns per cell (jittered grid: groups straddle two cells)
+    (2064, 30, 200, 4, 2),         # ~10 columns per cell: some group spans three cells -> bytes for the tile
+    (2048, 30, 1000, 4, 2),        # cells narrower than a pixel pair
+    (2051, 30, 82, 4, 1),          # W % 16 != 0: words are written, the strips read bytes all the same
+])
+def test_compact_soil_words_change_no_raster(eng9, tables, W, H, hsx, hsy, state):
+    """Strips of 16-byte aligned rows read one compact word per 16-px column group instead of 16 code bytes
+    when every group of the tile has at most two soil cells; otherwise, and with the option off, the bytes."""
+    esa, gt, coarse, sgt = make_block(W * 3 + hsx, H, W, hsy, hsx, nasty=True)
+    cases = [(1, 1 << 1), (2, 1 << 7), (3, 1 << 4), (3, 0x1ff), (2, 0b100100101), (1, 0x1ff)]
+    want = {c: oc.process_block_mem(esa, gt, coarse, sgt, tables, cond_mask=c[0], table_mask=c[1]) for c in cases}
+    try:
+        for on in (1, 0, 1):
+            eng9.set_option("compact_soil", on)
+            for c in cases:
+                got = eng9.process_block_mem(esa, gt, coarse, sgt, cond_mask=c[0], table_mask=c[1])
+                assert eng9.soil_words_state() == (state if on else 0)
+                assert np.array_equal(got, want[c]), (on, c)
+        # strips (the second one starts inside a soil row) and the launch shapes
+        eng9.set_option("compact_soil", 1)
+        for ilp1, pf, bpc, xcd in ((1, 1, 2, 1), (2, 0, 16, 0), (4, 0, 8, 1), (2, 1, 8, 1)):
+            for name, v in (("ilp1", ilp1), ("ilp16", min(ilp1, 2)), ("prefetch", pf), ("grid_blocks_per_cu", bpc),
+                            ("xcd_slabs", xcd)):
+                eng9.set_option(name, v)
+            for c in cases[:4]:
+                got = eng9.process_block_mem(esa, gt, coarse, sgt, cond_mask=c[0], table_mask=c[1], strip_rows=13)
+                assert np.array_equal(got, want[c]), (ilp1, pf, bpc, xcd, c)
+    finally:
+        eng9.set_option("defaults", 0)
+
+
+def test_compact_soil_words_with_a_column_map_that_is_not_monotone(eng9, tables):
+    """ci is the caller's: a decreasing map (a soil grid stored east to west) has compact groups as well, a
+    zig-zag one has none; both must give coarse[cj[y]][ci[x]] exactly."""
+    W, H, hsx, hsy = 2048, 24, 90, 6
+    rng = np.random.default_rng(17)
+    esa = rng.choice(np.array([10, 20, 30, 40, 50, 60, 70, 80, 90, 95, 100, 0, 255], dtype=np.uint8), size=(H, W))
+    coarse = rng.choice(np.array([0, 1, 2, 3, 4, 11, 12, 13, 14, 255, 7], dtype=np.uint8), size=(hsy, hsx))
+    cj = np.minimum(np.arange(H) * hsy // H, hsy - 1).astype(np.int32)
+    maps = {"decreasing": (hsx - 1 - np.arange(W) * hsx // W).astype(np.int32),
+            "zig-zag": ((np.arange(W) // 5) % 2 * 40 + np.arange(W) * 40 // W).astype(np.int32),
+            "constant": np.full(W, 17, dtype=np.int32)}
+    e = eng9
+    bufs = [e.upload(esa), e.upload(coarse), e.upload(cj)]
+    outs = [e.alloc(W * H) for _ in range(2)]
+    try:
+        for name, ci in maps.items():
+            d_ci = e.upload(ci)
+            e.prepare_tile(bufs[1].ptr, hsx, hsy, d_ci.ptr, W)
+            assert e.soil_words_state() == (2 if name == "zig-zag" else 1), name
+            ptrs = [None] * 18
+            ptrs[3], ptrs[9 + 3] = outs[0].ptr, outs[1].ptr
+            e.cn_strip(bufs[0].ptr, W, H, bufs[2].ptr, 3, 1 << 3, ptrs)
+            e.sync()
+            soil = coarse[cj][:, ci]
+            for c, drained in ((0, True), (1, False)):
+                want = oc.calculate_cn(esa, oc.modify_hysogs_data(soil, drained), tables[3])
+                assert np.array_equal(e.download(outs[c].ptr, (H, W)), want.reshape(H, W)), (name, c)
+            d_ci.close()
+    finally:
+        for b in bufs + outs:
+            b.close()
+
+
 def test_launch_shape_knobs_never_change_results(eng9, tables):
     """gcn10_gpu_set_option: chunks per trip, software pipeline, store policy, XCD slabs, grid size."""
     W, H = 3001, 53

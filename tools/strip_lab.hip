@@ -114,6 +114,12 @@ __device__ __forceinline__ void issue(const P &p, uint32_t trip, uint32_t lane16
             t.c[u] = u32x4{row, xl, 0u, 0u} & 0x01010101u;
             continue;
         }
+        if (DIAG & 4) {
+            // timing only: one dword per 16-px group {code a, code b, split} instead of 16 code bytes
+            const uint32_t w = *reinterpret_cast<const uint32_t *>(p.hx + (size_t)row * (p.hx_stride & ~15u) + (xl >> 2));
+            t.c[u] = u32x4{w, 0u, 0u, 0u};
+            continue;
+        }
         const uint8_t *pa = p.hx + (size_t)row * p.hx_stride + xl;
         u32x4 a = load16_any(pa);
         if (p.W & 15u) {
@@ -144,14 +150,26 @@ __device__ __forceinline__ void finish(const P &p, const uint8_t *lut, uint32_t 
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
         u32x4 v;
+        u32x4 cexp = t.c[u];
+        if (DIAG & 4) {
+            const uint32_t w = t.c[u][0];
+            const uint32_t a = (w & 0xffu) * 0x01010101u, b = ((w >> 8) & 0xffu) * 0x01010101u;
+            const int32_t split = (int32_t)((w >> 16) & 0x1fu);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int32_t m = split - 4 * j;
+                const uint32_t mask = m >= 4 ? 0xffffffffu : (m <= 0 ? 0u : (1u << (8 * m)) - 1u);
+                cexp[j] = (a & mask) | (b & ~mask);
+            }
+        }
         if (DIAG & 1) {
-            v = t.e[u] ^ t.c[u];
+            v = t.e[u] ^ cexp;
         }
         else {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t e = t.e[u][j];
-                const uint32_t cd = t.c[u][j];
+                const uint32_t cd = cexp[j];
                 uint32_t b[4];
                 if (LUTK == 2) {
                     const uint32_t m = (cd & 0x83838383u) | lane_rep;
@@ -448,7 +466,16 @@ __global__ __launch_bounds__(256) void copy_plus_kernel(const P p)
                 row = row < p.hx_rows ? row : p.hx_rows - 1u;
             }
             v[u] = __builtin_nontemporal_load(in + (idx[u] < nvec ? idx[u] : 0u));
-            if (LEVEL >= 2)
+            if (LEVEL == 4) {           // timing only: soil codes packed two per byte, one 8-byte load per lane
+                typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(1)));
+                const u32x2_u t = *reinterpret_cast<const u32x2_u *>(p.hx + (size_t)row * p.hx_stride + (xl >> 1));
+                h[u] = u32x4{t[0], t[1], 0u, 0u};
+            }
+            else if (LEVEL == 5) {      // timing only: four per byte, one 4-byte load per lane
+                typedef uint32_t u32_u __attribute__((aligned(1)));
+                h[u] = u32x4{*reinterpret_cast<const u32_u *>(p.hx + (size_t)row * p.hx_stride + (xl >> 2)), 0u, 0u, 0u};
+            }
+            else if (LEVEL >= 2)
                 h[u] = load16_any(p.hx + (size_t)row * p.hx_stride + xl);
             else
                 h[u] = u32x4{row, xl, 0u, 0u};
@@ -456,7 +483,7 @@ __global__ __launch_bounds__(256) void copy_plus_kernel(const P p)
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             u32x4 o;
-            if (LEVEL >= 3) {
+            if (LEVEL == 3) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     uint32_t b[4];
@@ -607,7 +634,7 @@ static void add_plus(Lab &L, int wg_per_cu, int out_idx = 0)
     char name[64];
     snprintf(name, sizeof name, "copy_plus_level%d_wg%d_out%d", LEVEL, wg_per_cu, out_idx);
     Variant v;
-    v.name = name; v.blocks = blocks; v.threads = 256; v.bytes = 2.0 * p.npix; v.check = LEVEL >= 3 ? p.out : nullptr;
+    v.name = name; v.blocks = blocks; v.threads = 256; v.bytes = 2.0 * p.npix; v.check = LEVEL == 3 ? p.out : nullptr;
     hipStream_t s = L.s;
     v.launch = [p, blocks, s](hipEvent_t a, hipEvent_t b) {
         P pp = p;
@@ -805,10 +832,14 @@ int main(int argc, char **argv)
     else if (!strcmp(set, "gap")) {
         // where is the strip kernel's time against the copy, in well-placed memory?
         add_copy<2, 256, 1>(L, 8); add_copy<2, 256, 1>(L, 16);
-        add_plus<1>(L, 8, 0); add_plus<2>(L, 8, 0); add_plus<3>(L, 8, 0);
+        add_plus<1>(L, 8, 0); add_plus<2>(L, 8, 0); add_plus<3>(L, 8, 0); add_plus<4>(L, 8, 0); add_plus<5>(L, 8, 0);
         add_variant<0, 2, true, 256, 0>(L, 8); add_variant<0, 2, true, 256, 0>(L, 16);
         add_variant<0, 4, false, 256, 0>(L, 16); add_variant<0, 2, false, 256, 0>(L, 8);
         add_variant<0, 1, true, 256, 0>(L, 16); add_variant<0, 4, true, 256, 0>(L, 8);
+        add_variant<0, 2, true, 256, 4>(L, 8);              // timing only: compact soil words (4 B per 16 px)
+        add_variant<0, 4, false, 256, 4>(L, 16);
+        add_variant<0, 4, true, 256, 4>(L, 8);
+        add_variant<0, 2, true, 256, 4>(L, 16);
         add_variant<0, 2, true, 256, 1>(L, 8);              // timing only: no gather / no soil load / neither
         add_variant<0, 2, true, 256, 2>(L, 8);
         add_variant<0, 2, true, 256, 3>(L, 8);

@@ -24,6 +24,12 @@ outs = {"plain": eng.alloc(npix), "spread": eng.alloc_spread(npix, 32 << 20, 256
 eng.prepare_tile(d_coarse.ptr, hs, hs, d_ci.ptr, size)
 ev = [(eng.event_create(), eng.event_create()) for _ in range(5)]
 variants = [("flat ilp2 pf bpc8", dict(ilp1=2, prefetch=1, grid_blocks_per_cu=8)),
+            ("flat ilp2 pf bpc8, soil BYTES", dict(ilp1=2, prefetch=1, grid_blocks_per_cu=8, compact_soil=0)),
+            ("flat ilp4 bpc16, soil BYTES", dict(ilp1=4, prefetch=0, grid_blocks_per_cu=16, compact_soil=0)),
+            ("flat ilp2 pf bpc16", dict(ilp1=2, prefetch=1, grid_blocks_per_cu=16)),
+            ("flat ilp2 pf bpc16, soil BYTES", dict(ilp1=2, prefetch=1, grid_blocks_per_cu=16, compact_soil=0)),
+            ("flat ilp1 pf bpc16", dict(ilp1=1, prefetch=1, grid_blocks_per_cu=16)),
+            ("flat ilp4 bpc8", dict(ilp1=4, prefetch=0, grid_blocks_per_cu=8)),
             ("flat ilp2 pf bpc8, prepare_tile before every launch", dict(ilp1=2, prefetch=1, grid_blocks_per_cu=8, PREP=1)),
             ("flat ilp4 bpc16", dict(ilp1=4, prefetch=0, grid_blocks_per_cu=16)),
             ("flat ilp4 bpc16, prepare_tile before every launch", dict(ilp1=4, prefetch=0, grid_blocks_per_cu=16, PREP=1)),
