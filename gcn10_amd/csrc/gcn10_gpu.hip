@@ -77,8 +77,9 @@ struct StripParams {
     uint32_t xcd_slabs;     // 1: each XCD streams a contiguous eighth of the strip
     // compact soil words (one dword per 16-px column group, see expand_x_codes); hx4 = null: not in use
     const uint32_t *hx4;
-    const uint32_t *hx4_complex;    // device flag: nonzero = some group of the tile has no compact form
+    const uint32_t *hx4_complex;    // device word: == hx4_gen when some group of the tile has no compact form
     uint32_t hx4_stride;            // dwords per soil row
+    uint32_t hx4_gen;               // generation number of the prepared tile (never 0)
 };
 
 // soil code byte: low nibble = plane for "drained", high nibble = "undrained".
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(kThreads) void cn_strip_kernel(const StripParams p)
 
     // compact soil words when the host offers them and no column group of this tile is complex
     // (wave-uniform: the flag comes through the scalar cache)
-    if (p.hx4 && scalar_load_i32(reinterpret_cast<const int32_t *>(p.hx4_complex), 0u) == 0)
+    if (p.hx4 && (uint32_t)scalar_load_i32(reinterpret_cast<const int32_t *>(p.hx4_complex), 0u) != p.hx4_gen)
         strip_loop<KIND, COND_MASK, ILP, NT, PF, true>(p, lut, tmask, lane_off, wave_off);
     else
         strip_loop<KIND, COND_MASK, ILP, NT, PF, false>(p, lut, tmask, lane_off, wave_off);
@@ -554,8 +555,10 @@ __global__ __launch_bounds__(kThreads) void cn_strip_bytes(const StripParams p,
 // then load one dword per lane instead of 16 bytes (the soil stream costs the
 // single-raster kernel 5 % with bytes, 1-2 % with words: DESIGN.md section 5).
 // A group that has no such form (three cells under 16 columns, a map that is
-// not monotone) gets split = 0xff and raises *complex; the strip kernels read
-// that flag and use the bytes for the whole tile.
+// not monotone) gets split = 0xff and stores this tile's generation number in
+// *complex (no reset between tiles needed); the strip kernels compare that
+// word with the generation they were launched for and use the bytes for the
+// whole tile when it matches.
 // ------------------------------------------------------------------------
 constexpr uint32_t kExpandRows = 2;     // coarse rows per thread of expand_x_codes
 
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(kThreads) void expand_x_codes(const uint8_t *coarse
                                                            uint32_t hsx, uint32_t hsy,
                                                            const int32_t *ci, uint32_t W,
                                                            uint8_t *hx, uint32_t hx_stride,
-                                                           uint32_t *hx4, uint32_t *complex)
+                                                           uint32_t *hx4, uint32_t *complex, uint32_t gen)
 {
     // one thread = 16 consecutive fine columns of kExpandRows coarse rows: the 16 column indices are
     // loaded once (dwordx4 when ci is 16-byte aligned) and clamped once, then per row 16 byte gathers
@@ -610,8 +613,8 @@ __global__ __launch_bounds__(kThreads) void expand_x_codes(const uint8_t *coarse
         split += lo && split == (uint32_t)q ? 1u : 0u;
     }
     const bool two = c_lo != 0xffffffffu && c_hi != 0xffffffffu && in_set;
-    if (hx4 && x < W && !compact && *reinterpret_cast<volatile uint32_t *>(complex) == 0u)
-        atomicOr(complex, 1u);
+    if (hx4 && x < W && !compact && *reinterpret_cast<volatile uint32_t *>(complex) != gen)
+        *reinterpret_cast<volatile uint32_t *>(complex) = gen;      // every writer stores the same value
     for (uint32_t r = r0; r < r1; r++) {
         const uint8_t *row = coarse + (size_t)r * hsx;
         u32x4 o;
@@ -639,10 +642,10 @@ __global__ __launch_bounds__(kThreads) void expand_x_codes(const uint8_t *coarse
                 o[j] = w;
             }
         }
-        *reinterpret_cast<u32x4 *>(hx + (size_t)r * hx_stride + x) = o;
+        __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(hx + (size_t)r * hx_stride + x));
         if (hx4)
-            hx4[(size_t)r * (hx_stride / 16u) + x / 16u] =
-                compact ? (o[0] & 0xffu) | ((o[3] >> 24) << 8) | (split << 16) : 0x00ff0000u;
+            __builtin_nontemporal_store(compact ? (o[0] & 0xffu) | ((o[3] >> 24) << 8) | (split << 16) : 0x00ff0000u,
+                                        hx4 + (size_t)r * (hx_stride / 16u) + x / 16u);
     }
 }
 
@@ -1510,12 +1513,14 @@ int gcn10_gpu_prepare_tile(gcn10_gpu_ctx *ctx, const uint8_t *coarse, int hsx, i
         ctx->d_hx = ctx->d_hx_alloc + 16;
         ctx->d_hx4 = reinterpret_cast<uint32_t *>(ctx->d_hx + need16);
         ctx->d_hx4_complex = reinterpret_cast<uint32_t *>(ctx->d_hx + need16 + need16 / 4);
+        HIP_TRY(hipMemset(ctx->d_hx4_complex, 0, 4));
+        ctx->hx4_gen = 0;
         ctx->hx_capacity = need;
     }
     uint32_t *hx4 = ctx->compact_soil ? ctx->d_hx4 : nullptr;
     ctx->hx4_ready = hx4 != nullptr;
-    if (hx4)
-        HIP_TRY(hipMemsetAsync(ctx->d_hx4_complex, 0, 4, as_stream(ctx, stream)));
+    if (hx4 && ++ctx->hx4_gen == 0u)
+        ctx->hx4_gen = 1u;      // 0 is what the word holds before the first complex tile
     ctx->hx_stride = stride;
     ctx->hx_W = (uint32_t)W;
     ctx->hx_rows = (uint32_t)hsy;
@@ -1523,11 +1528,11 @@ int gcn10_gpu_prepare_tile(gcn10_gpu_ctx *ctx, const uint8_t *coarse, int hsx, i
     if (aligned16(ci))
         hipLaunchKernelGGL(expand_x_codes<true>, grid, dim3(kThreads), 0, as_stream(ctx, stream),
                            coarse, (uint32_t)hsx, (uint32_t)hsy, ci, (uint32_t)W, ctx->d_hx, stride, hx4,
-                           ctx->d_hx4_complex);
+                           ctx->d_hx4_complex, ctx->hx4_gen);
     else
         hipLaunchKernelGGL(expand_x_codes<false>, grid, dim3(kThreads), 0, as_stream(ctx, stream),
                            coarse, (uint32_t)hsx, (uint32_t)hsy, ci, (uint32_t)W, ctx->d_hx, stride, hx4,
-                           ctx->d_hx4_complex);
+                           ctx->d_hx4_complex, ctx->hx4_gen);
     HIP_TRY(hipGetLastError());
     return GCN10_OK;
 }
@@ -1591,6 +1596,7 @@ int gcn10_gpu_cn_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W, int rows,
         p.hx4 = ctx->d_hx4;
         p.hx4_complex = ctx->d_hx4_complex;
         p.hx4_stride = ctx->hx_stride / 16u;
+        p.hx4_gen = ctx->hx4_gen;
     }
     // the vector kernel wants a wave's 1024-px span to cross at most one row end
     if (p.npix < 16u || p.W < kMinVectorW)
@@ -1859,7 +1865,7 @@ int gcn10_gpu_soil_words_state(gcn10_gpu_ctx *ctx, gcn10_stream_t stream)
     hipStream_t s = as_stream(ctx, stream);
     HIP_TRY(hipMemcpyAsync(&flag, ctx->d_hx4_complex, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    return flag ? 2 : 1;
+    return flag == ctx->hx4_gen ? 2 : 1;
 }
 
 const char *gcn10_gpu_last_kernel_name(gcn10_gpu_ctx *ctx)

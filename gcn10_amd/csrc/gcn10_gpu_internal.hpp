@@ -43,7 +43,8 @@ struct gcn10_gpu_ctx {
     uint8_t *d_hx = nullptr;        // row 0 of the soil-code workspace (= d_hx_alloc + 16)
     uint8_t *d_hx_alloc = nullptr;
     uint32_t *d_hx4 = nullptr;          // compact soil words, one per 16-px column group and coarse row
-    uint32_t *d_hx4_complex = nullptr;  // device flag: some group of the prepared tile has no compact form
+    uint32_t *d_hx4_complex = nullptr;  // device word: == hx4_gen when some group of the prepared tile has no compact form
+    uint32_t hx4_gen = 0;               // generation number of the prepared tile
     bool hx4_ready = false;             // the last gcn10_gpu_prepare_tile wrote the words
     int compact_soil = 1;               // option: write and use the compact words
     size_t hx_capacity = 0;
