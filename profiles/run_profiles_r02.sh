@@ -13,13 +13,13 @@ cd /tmp && export TMPDIR=/tmp
 K=20
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps $K --warmup 5 --no-cpu-baseline > $O/kt.json 2> $O/kt.err
 echo kt done
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/fetch.json 2> $O/fetch.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 4 --warmup 1 --pre-warm-ms 0 --no-cpu-baseline > $O/fetch.json 2> $O/fetch.err
 echo fetch done
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/write.json 2> $O/write.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --steps 4 --warmup 1 --pre-warm-ms 0 --no-cpu-baseline > $O/write.json 2> $O/write.err
 echo write done
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $O/sq1 -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/sq1.json 2> $O/sq1.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $O/sq1 -- python3 $R/bench.py --steps 4 --warmup 1 --pre-warm-ms 0 --no-cpu-baseline > $O/sq1.json 2> $O/sq1.err
 echo sq1 done
-rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/sq2 -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/sq2.json 2> $O/sq2.err
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/sq2 -- python3 $R/bench.py --steps 4 --warmup 1 --pre-warm-ms 0 --no-cpu-baseline > $O/sq2.json 2> $O/sq2.err
 echo sq2 done
 python3 $R/bench.py --steps $K --warmup 5 > $O/bench_final.json 2> $O/bench_final.err
 echo bench done
