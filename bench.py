@@ -231,8 +231,10 @@ def launch_ranks(args, argv):
 
 
 # (chunk bytes, ballast bytes, ballast after every n chunks) of the spread candidates the calibration tries
+# (after every -1 = two pools `ballast` apart, their chunks taken alternately)
 SPREAD_RECIPES = [(32 << 20, 256 << 20, 1), (32 << 20, 1 << 30, 1), (8 << 20, 256 << 20, 1), (128 << 20, 2 << 30, 1),
-                  (2 << 20, 64 << 20, 1), (32 << 20, 0, 1)]
+                  (2 << 20, 64 << 20, 1), (32 << 20, 0, 1), (32 << 20, 16 << 30, -1), (32 << 20, 8 << 30, -1),
+                  (8 << 20, 24 << 30, -1)]
 
 
 def _placement_label(kind):
@@ -241,6 +243,8 @@ def _placement_label(kind):
     if kind == "contiguous":
         return "contiguous"
     _, chunk, gap, every = kind
+    if every == -1:
+        return "spread: %d MiB chunks alternately from two pools %d MiB apart" % (chunk >> 20, gap >> 20)
     return "spread: %d MiB chunks, %d MiB ballast after every %d" % (chunk >> 20, gap >> 20, every)
 
 
@@ -359,13 +363,19 @@ def main(argv=None):
                     # physical chunks lie far apart is written faster than one inside a contiguous extent
                     # (include/gcn10_gpu.h, gcn10_gpu_malloc_spread; tools/spread_lab.hip).  The candidates are
                     # a few plain allocations and one raster per spread recipe.
+                    # (Contiguous rasters allocated while 2 ... 32 GiB of ballast were held, to land in the
+                    # other class of VRAM region than the landcover, ran at 0.45-0.48 ms in three processes:
+                    # profiles/r02/bench_candidates_with_offset_contiguous_{1,2,3}.json; not offered any more.)
                     kinds = [None] * max(1, args.tune_arenas)
                     if hasattr(eng, "alloc_spread") and not args.no_spread:
                         kinds += [("spread",) + rcp for rcp in SPREAD_RECIPES]
                     cands, cand_kinds = [], []
                     for kind in kinds:
                         try:
-                            cands.append(eng.alloc(npix + slack) if kind is None else eng.alloc(npix + slack, kind))
+                            if kind is None:
+                                cands.append(eng.alloc(npix + slack))
+                            else:
+                                cands.append(eng.alloc(npix + slack, kind))
                             cand_kinds.append(_placement_label(kind))
                         except Exception as exc:       # a recipe the device refuses is one candidate fewer
                             sys.stderr.write("bench.py: candidate %s skipped (%s)\n" % (_placement_label(kind), exc))

@@ -1056,8 +1056,9 @@ int gcn10_gpu_malloc_spread(gcn10_gpu_ctx *ctx, size_t bytes, size_t chunk_bytes
     if (!dptr)
         return fail(GCN10_E_INVAL, "gcn10_gpu_malloc_spread: null out pointer");
     *dptr = nullptr;
-    if (gap_every < 0)
+    if (gap_every < -1)
         return fail(GCN10_E_INVAL, "gcn10_gpu_malloc_spread: gap_every %d", gap_every);
+    const bool two_pools = gap_every == -1;
     if (!bytes)
         bytes = 1;
     if (!chunk_bytes)
@@ -1091,17 +1092,16 @@ int gcn10_gpu_malloc_spread(gcn10_gpu_ctx *ctx, size_t bytes, size_t chunk_bytes
     std::vector<void *> ballast;
     bool ballast_ok = gap_bytes != 0;
     sp.handles.reserve(n);
+    // creation: chunk by chunk, ballast in between (after every gap_every chunks, or once in the middle)
+    const size_t half = (n + 1) / 2;
     for (size_t i = 0; i < n && e == hipSuccess; i++) {
         hipMemGenericAllocationHandle_t h;
         e = hipMemCreate(&h, chunk, &prop, 0);
         if (e != hipSuccess)
             break;
         sp.handles.push_back(h);
-        e = hipMemMap(sp.va + i * chunk, chunk, 0, h, 0);
-        if (e != hipSuccess)
-            break;
-        sp.mapped = i + 1;
-        if (ballast_ok && i + 1 < n && (i + 1) % (size_t)gap_every == 0) {
+        const bool gap_here = two_pools ? i + 1 == half : (i + 1) % (size_t)gap_every == 0;
+        if (ballast_ok && i + 1 < n && gap_here) {
             void *b = nullptr;
             if (hipMalloc(&b, gap_bytes) == hipSuccess)
                 ballast.push_back(b);
@@ -1110,6 +1110,14 @@ int gcn10_gpu_malloc_spread(gcn10_gpu_ctx *ctx, size_t bytes, size_t chunk_bytes
                 ballast_ok = false;
             }
         }
+    }
+    // mapping: creation order, or the chunks of the two pools alternately
+    for (size_t i = 0; i < sp.handles.size() && e == hipSuccess && sp.handles.size() == n; i++) {
+        const size_t k = two_pools ? ((i & 1u) ? half + i / 2 : i / 2) : i;
+        e = hipMemMap(sp.va + i * chunk, chunk, 0, sp.handles[k < n ? k : i], 0);
+        if (e != hipSuccess)
+            break;
+        sp.mapped = i + 1;
     }
     if (e == hipSuccess) {
         hipMemAccessDesc acc = {};

@@ -91,6 +91,10 @@ int gcn10_gpu_malloc(gcn10_gpu_ctx *ctx, size_t bytes, void **dptr);
  *                mapping granularity; 0 = 32 MiB) created one by one, with `gap_bytes` of ballast allocated after
  *                every `gap_every` chunks (0 = 1) and released again before the call returns, so that consecutive
  *                chunks come from places `gap_bytes` apart.  gap_bytes = 0 builds the range without ballast.
+ *                gap_every = -1: TWO POOLS -- the first half of the chunks, one ballast of gap_bytes, the
+ *                second half; the range then takes its chunks from the two pools alternately (VRAM comes in
+ *                two classes of region that alternate every ~16 GiB of allocation order; a raster that mixes
+ *                both is written fastest).
  *                Ballast the device cannot supply is skipped, not an error.  GCN10_E_HIP when the device has no
  *                virtual memory management. */
 int gcn10_gpu_malloc_contiguous(gcn10_gpu_ctx *ctx, size_t bytes, void **dptr);

@@ -304,7 +304,7 @@ def test_placed_allocations_hold_the_same_rasters(eng9, tables):
     for round_ in range(3):
         bufs = [e.upload(esa, placement="contiguous"), e.upload(coarse), e.upload(ci), e.upload(cj)]
         outs = {}
-        recipes = [(2 << 20, 0, 1), (2 << 20, 8 << 20, 1), (4 << 20, 16 << 20, 2), (0, 64 << 20, 1)]
+        recipes = [(2 << 20, 0, 1), (2 << 20, 8 << 20, -1), (4 << 20, 16 << 20, 2), (0, 64 << 20, 1)]
         for k, r in enumerate((2, 8, 9 + 2, 9 + 8)):
             chunk, gap, every = recipes[k]
             outs[r] = e.alloc_spread(npix + 64, chunk, gap, every)
@@ -331,7 +331,7 @@ def test_placed_allocations_hold_the_same_rasters(eng9, tables):
             for b in bufs + list(outs.values()):
                 b.close()
     with pytest.raises(gpu.Gcn10GpuError):
-        e.alloc_spread(1 << 20, 1 << 20, 0, -1)
+        e.alloc_spread(1 << 20, 1 << 20, 0, -2)
 
 
 @pytest.mark.parametrize("n_tables", [1, 2, 5, 9])
