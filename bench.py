@@ -230,24 +230,6 @@ def launch_ranks(args, argv):
         raise SystemExit("bench.py: rank(s) failed: %s" % ", ".join("rank %d rc %d" % b for b in failed))
 
 
-# (chunk bytes, ballast bytes, ballast after every n chunks) of the spread candidates the calibration tries
-# (after every -1 = two pools `ballast` apart, their chunks taken alternately)
-SPREAD_RECIPES = [(32 << 20, 256 << 20, 1), (32 << 20, 1 << 30, 1), (8 << 20, 256 << 20, 1), (128 << 20, 2 << 30, 1),
-                  (2 << 20, 64 << 20, 1), (32 << 20, 0, 1), (32 << 20, 16 << 30, -1), (32 << 20, 8 << 30, -1),
-                  (8 << 20, 24 << 30, -1)]
-
-
-def _placement_label(kind):
-    if kind is None:
-        return "plain"
-    if kind == "contiguous":
-        return "contiguous"
-    _, chunk, gap, every = kind
-    if every == -1:
-        return "spread: %d MiB chunks alternately from two pools %d MiB apart" % (chunk >> 20, gap >> 20)
-    return "spread: %d MiB chunks, %d MiB ballast after every %d" % (chunk >> 20, gap >> 20, every)
-
-
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
@@ -265,14 +247,12 @@ def main(argv=None):
                          "its rows (rows are independent given cj[], src/cn.c:218-232)")
     ap.add_argument("--no-tune", action="store_true",
                     help="skip the placement / launch-shape calibration of the one-raster workload")
-    ap.add_argument("--tune-arenas", type=int, default=5,
+    ap.add_argument("--tune-arenas", type=int, default=24,
                     help="candidate allocations the calibration chooses the raster buffer from")
     ap.add_argument("--tune-sources", type=int, default=3,
                     help="placements of the landcover block the calibration chooses from")
     ap.add_argument("--pre-warm-ms", type=float, default=150.0,
                     help="untimed steps run for this long before the W warm-up steps (clock ramp after the set-up)")
-    ap.add_argument("--no-spread", action="store_true",
-                    help="calibration: plain allocations only (no gcn10_gpu_malloc_spread candidates)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="rehearsal: let ranks share GPUs (rank r uses device r mod visible devices)")
     args = ap.parse_args(argv)
@@ -336,8 +316,6 @@ def main(argv=None):
     outs = [None] * 18
     out_bufs = []
     placement = None
-    out_placement = None    # how the calibration's winning raster was allocated (None = gcn10_gpu_malloc)
-    esa_kind = "plain"
     # (A/B switch: allocating the 17 extra rasters of the config4 leg BEFORE the calibration's candidates put
     # every candidate in a slow place in both processes that tried it -- 0.484 ms against 0.438-0.465 ms,
     # profiles/r02/bench_alloc_order_ab.txt -- so they are allocated after it)
@@ -350,7 +328,7 @@ def main(argv=None):
     for r in range(18):
         if (cond_mask >> (r // 9)) & 1 and (table_mask >> (r % 9)) & 1:
             if tune:
-                cands = []
+                cands, spacers = [], []
                 try:
                     # a one-raster strip is a 1R:1W stream whose rate depends on where the raster lies
                     # relative to the landcover -- within an allocation periodically in the distance (128 MiB),
@@ -359,26 +337,22 @@ def main(argv=None):
                     # (and its launch shapes); keep the best allocation, free the others.
                     slack = 160 << 20
                     eng.prepare_tile(d_coarse.ptr, hs, hs, d_ci.ptr, size)
-                    # ... and by up to 12 % with HOW the raster is spread over VRAM: a written raster whose
-                    # physical chunks lie far apart is written faster than one inside a contiguous extent
-                    # (include/gcn10_gpu.h, gcn10_gpu_malloc_spread; tools/spread_lab.hip).  The candidates are
-                    # a few plain allocations and one raster per spread recipe.
-                    # (Contiguous rasters allocated while 2 ... 32 GiB of ballast were held, to land in the
-                    # other class of VRAM region than the landcover, ran at 0.45-0.48 ms in three processes:
-                    # profiles/r02/bench_candidates_with_offset_contiguous_{1,2,3}.json; not offered any more.)
-                    kinds = [None] * max(1, args.tune_arenas)
-                    if hasattr(eng, "alloc_spread") and not args.no_spread:
-                        kinds += [("spread",) + rcp for rcp in SPREAD_RECIPES]
-                    cands, cand_kinds = [], []
-                    for kind in kinds:
+                    # (Rasters assembled from far-apart physical chunks through HIP's virtual memory management
+                    # ran this kernel at 0.416-0.427 ms on boxes where every plain candidate runs at 0.48 ms, but
+                    # nontemporal stores into such ranges were not reliably visible when the kernel had completed:
+                    # profiles/r02/spread_allocator_hazard.txt.  Plain allocations only.)
+                    # VRAM comes in two classes of region that alternate every ~16 GiB of allocation order, and
+                    # a raster in the class the landcover is not in is written 6-12 % faster
+                    # (tools/region_lab.hip): the candidates are all held until the choice is made, with a
+                    # 2 GiB spacer after every fourth, so that twenty-four of them span ~47 GiB.
+                    cands, spacers = [], []
+                    for k in range(max(1, args.tune_arenas)):
                         try:
-                            if kind is None:
-                                cands.append(eng.alloc(npix + slack))
-                            else:
-                                cands.append(eng.alloc(npix + slack, kind))
-                            cand_kinds.append(_placement_label(kind))
-                        except Exception as exc:       # a recipe the device refuses is one candidate fewer
-                            sys.stderr.write("bench.py: candidate %s skipped (%s)\n" % (_placement_label(kind), exc))
+                            cands.append(eng.alloc(npix + slack))
+                            if k % 4 == 3:
+                                spacers.append(eng.alloc(2 << 30))
+                        except Exception as exc:
+                            sys.stderr.write("bench.py: candidate skipped (%s)\n" % exc)
                     if not cands:
                         raise RuntimeError("no candidate raster could be allocated")
                     tried = []
@@ -390,8 +364,9 @@ def main(argv=None):
                     for i, c in enumerate(cands):
                         if i != keep:
                             c.close()
+                    for sp in spacers:
+                        sp.close()
                     b = cands[keep]
-                    out_placement = b.placement if hasattr(b, "placement") else None
                     out_bufs.append(b)
                     # once more on the winner: leaves ITS best launch shape set in the context
                     best, best_ms, placement = eng.tune_single_raster(d_esa.ptr, size, rows_mine, d_cj.ptr, cond_mask,
@@ -401,25 +376,15 @@ def main(argv=None):
                     # ... and where the landcover lies matters too (some allocations read or write a few
                     # percent faster than others whatever their partner, profiles/r02/placement_probe2_*):
                     # the same block uploaded to one or two more places, each timed against the chosen raster
-                    # (a raster that is only read is read fastest from one contiguous extent: that placement is
-                    # the first alternative tried)
                     src_ms = [round(best_ms, 4)]
-                    src_kinds = ["plain"]
                     for k in range(max(0, args.tune_sources - 1)):
-                        src_kind = "contiguous" if k == 0 and hasattr(eng, "alloc_contiguous") else None
-                        try:
-                            alt = eng.upload(esa_host) if src_kind is None else eng.upload(esa_host, placement=src_kind)
-                        except Exception as exc:
-                            sys.stderr.write("bench.py: landcover placement %s skipped (%s)\n" % (src_kind, exc))
-                            continue
-                        src_kinds.append(_placement_label(src_kind))
+                        alt = eng.upload(esa_host)
                         a_best, a_ms, a_rep = eng.tune_single_raster(alt.ptr, size, rows_mine, d_cj.ptr, cond_mask,
                                                                      table_mask, b.ptr, npix + slack, 16 << 20)
                         src_ms.append(round(a_ms, 4))
                         if a_ms < best_ms * 0.995:
                             d_esa.close()
                             d_esa, best_ms, outs[r] = alt, a_ms, a_best
-                            esa_kind = src_kinds[-1]
                         else:
                             alt.close()
                     # the shape left in the context belongs to the last call: set the winner's again
@@ -427,15 +392,11 @@ def main(argv=None):
                                                                 table_mask, b.ptr, npix + slack, 16 << 20)
                     outs[r] = best
                     rep["allocations_tried_best_ms"] = tried
-                    rep["allocations_tried_kinds"] = cand_kinds
-                    rep["raster_placement"] = cand_kinds[keep]
                     rep["landcover_placements_tried_best_ms"] = src_ms
-                    rep["landcover_placements_tried_kinds"] = src_kinds
-                    rep["landcover_placement"] = esa_kind
                     placement = rep
                 except Exception as exc:       # the calibration is an optimisation: never lose the bench line over it
                     sys.stderr.write("bench.py: placement calibration skipped (%s)\n" % exc)
-                    for c in cands:
+                    for c in cands + spacers:
                         try:
                             c.close()
                         except Exception:
@@ -454,13 +415,7 @@ def main(argv=None):
     del esa_host
     if want_also and not extra:
         # the extra config4 measurement writes 18 rasters: allocate the other 17 now, long before they are timed
-        # (placed like the calibration's winner when that was a spread raster: they are written, never read)
-        for _ in range(17):
-            try:
-                extra.append(eng.alloc(npix) if out_placement is None else eng.alloc(npix, out_placement))
-            except Exception as exc:
-                sys.stderr.write("bench.py: extra raster falls back to a plain allocation (%s)\n" % exc)
-                extra.append(eng.alloc(npix))
+        extra = [eng.alloc(npix) for _ in range(17)]
     d_fine = None
     if preresampled:
         d_fine = eng.alloc(npix)

@@ -29,6 +29,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -940,8 +941,6 @@ int gcn10_gpu_init(int device, gcn10_gpu_ctx **out)
     return GCN10_OK;
 }
 
-static int spread_release(gcn10_gpu_ctx::Spread &sp);
-
 void gcn10_gpu_destroy(gcn10_gpu_ctx *ctx)
 {
     if (!ctx)
@@ -963,11 +962,6 @@ void gcn10_gpu_destroy(gcn10_gpu_ctx *ctx)
         (void)hipFree(ctx->inflate_ws);
     if (ctx->d_class_of)
         (void)hipFree(ctx->d_class_of);
-    if (!ctx->spread.empty()) {
-        (void)hipDeviceSynchronize();
-        for (auto &sp : ctx->spread)
-            (void)spread_release(sp);
-    }
     delete ctx;
 }
 
@@ -1007,153 +1001,13 @@ int gcn10_gpu_malloc(gcn10_gpu_ctx *ctx, size_t bytes, void **dptr)
     return GCN10_OK;
 }
 
-int gcn10_gpu_malloc_contiguous(gcn10_gpu_ctx *ctx, size_t bytes, void **dptr)
-{
-    int rc = use_device(ctx);
-    if (rc)
-        return rc;
-    if (!dptr)
-        return fail(GCN10_E_INVAL, "gcn10_gpu_malloc_contiguous: null out pointer");
-    *dptr = nullptr;
-    HIP_TRY(hipExtMallocWithFlags(dptr, bytes ? bytes : 1, hipDeviceMallocContiguous));
-    return GCN10_OK;
-}
-
-// Unmaps, releases and un-reserves one spread buffer (also the unwinding path of a build that failed half-way:
-// only `mapped` chunks are mapped, every handle in `handles` exists).
-static int spread_release(gcn10_gpu_ctx::Spread &sp)
-{
-    hipError_t first = hipSuccess;
-    for (size_t i = 0; i < sp.mapped; i++) {
-        hipError_t e = hipMemUnmap(sp.va + i * sp.chunk, sp.chunk);
-        if (e != hipSuccess && first == hipSuccess)
-            first = e;
-    }
-    for (hipMemGenericAllocationHandle_t h : sp.handles) {
-        hipError_t e = hipMemRelease(h);
-        if (e != hipSuccess && first == hipSuccess)
-            first = e;
-    }
-    if (sp.va) {
-        hipError_t e = hipMemAddressFree(sp.va, sp.size);
-        if (e != hipSuccess && first == hipSuccess)
-            first = e;
-    }
-    sp = gcn10_gpu_ctx::Spread();
-    if (first != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(GCN10_E_HIP, "releasing a spread buffer: %s", hipGetErrorString(first));
-    }
-    return GCN10_OK;
-}
-
-int gcn10_gpu_malloc_spread(gcn10_gpu_ctx *ctx, size_t bytes, size_t chunk_bytes, size_t gap_bytes, int gap_every,
-                            void **dptr)
-{
-    int rc = use_device(ctx);
-    if (rc)
-        return rc;
-    if (!dptr)
-        return fail(GCN10_E_INVAL, "gcn10_gpu_malloc_spread: null out pointer");
-    *dptr = nullptr;
-    if (gap_every < -1)
-        return fail(GCN10_E_INVAL, "gcn10_gpu_malloc_spread: gap_every %d", gap_every);
-    const bool two_pools = gap_every == -1;
-    if (!bytes)
-        bytes = 1;
-    if (!chunk_bytes)
-        chunk_bytes = (size_t)32 << 20;
-    if (!gap_every)
-        gap_every = 1;
-    hipMemAllocationProp prop = {};
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = ctx->device;
-    size_t gran = 0;
-    hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
-    if (e != hipSuccess || !gran) {
-        (void)hipGetLastError();
-        return fail(GCN10_E_HIP, "gcn10_gpu_malloc_spread: no virtual memory management on device %d (%s)", ctx->device,
-                    hipGetErrorString(e));
-    }
-    if (chunk_bytes > ((size_t)1 << 40) || bytes > ((size_t)1 << 44))
-        return fail(GCN10_E_INVAL, "gcn10_gpu_malloc_spread: %zu bytes in chunks of %zu", bytes, chunk_bytes);
-    const size_t chunk = (chunk_bytes + gran - 1) / gran * gran;
-    const size_t n = (bytes + chunk - 1) / chunk;
-    gcn10_gpu_ctx::Spread sp;
-    sp.chunk = chunk;
-    sp.size = n * chunk;
-    e = hipMemAddressReserve((void **)&sp.va, sp.size, 0, nullptr, 0);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(GCN10_E_HIP, "gcn10_gpu_malloc_spread: reserving %zu bytes of address space: %s", sp.size,
-                    hipGetErrorString(e));
-    }
-    std::vector<void *> ballast;
-    bool ballast_ok = gap_bytes != 0;
-    sp.handles.reserve(n);
-    // creation: chunk by chunk, ballast in between (after every gap_every chunks, or once in the middle)
-    const size_t half = (n + 1) / 2;
-    for (size_t i = 0; i < n && e == hipSuccess; i++) {
-        hipMemGenericAllocationHandle_t h;
-        e = hipMemCreate(&h, chunk, &prop, 0);
-        if (e != hipSuccess)
-            break;
-        sp.handles.push_back(h);
-        const bool gap_here = two_pools ? i + 1 == half : (i + 1) % (size_t)gap_every == 0;
-        if (ballast_ok && i + 1 < n && gap_here) {
-            void *b = nullptr;
-            if (hipMalloc(&b, gap_bytes) == hipSuccess)
-                ballast.push_back(b);
-            else {
-                (void)hipGetLastError();    // the card is full: go on without further ballast
-                ballast_ok = false;
-            }
-        }
-    }
-    // mapping: creation order, or the chunks of the two pools alternately
-    for (size_t i = 0; i < sp.handles.size() && e == hipSuccess && sp.handles.size() == n; i++) {
-        const size_t k = two_pools ? ((i & 1u) ? half + i / 2 : i / 2) : i;
-        e = hipMemMap(sp.va + i * chunk, chunk, 0, sp.handles[k < n ? k : i], 0);
-        if (e != hipSuccess)
-            break;
-        sp.mapped = i + 1;
-    }
-    if (e == hipSuccess) {
-        hipMemAccessDesc acc = {};
-        acc.location = prop.location;
-        acc.flags = hipMemAccessFlagsProtReadWrite;
-        e = hipMemSetAccess(sp.va, sp.size, &acc, 1);
-    }
-    for (void *b : ballast)
-        (void)hipFree(b);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        (void)spread_release(sp);
-        return fail(GCN10_E_HIP, "gcn10_gpu_malloc_spread: %zu bytes in %zu chunks of %zu: %s", bytes, n, chunk,
-                    hipGetErrorString(e));
-    }
-    *dptr = sp.va;
-    ctx->spread.push_back(std::move(sp));
-    return GCN10_OK;
-}
-
 int gcn10_gpu_free(gcn10_gpu_ctx *ctx, void *dptr)
 {
     int rc = use_device(ctx);
     if (rc)
         return rc;
-    if (!dptr)
-        return GCN10_OK;
-    for (size_t i = 0; i < ctx->spread.size(); i++)
-        if (ctx->spread[i].va == dptr) {
-            // nothing may still be running on the range when its chunks go away
-            HIP_TRY(hipDeviceSynchronize());
-            rc = spread_release(ctx->spread[i]);
-            ctx->spread.erase(ctx->spread.begin() + (long)i);
-            return rc;
-        }
-    HIP_TRY(hipFree(dptr));
+    if (dptr)
+        HIP_TRY(hipFree(dptr));
     return GCN10_OK;
 }
 

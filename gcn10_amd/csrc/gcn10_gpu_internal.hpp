@@ -5,7 +5,6 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
-#include <vector>
 
 #include "gcn10_gpu.h"
 
@@ -81,14 +80,6 @@ struct gcn10_gpu_ctx {
     size_t deflate_ws_cap = 0;
     void *inflate_ws = nullptr;     // linear slots of the tiles being decoded (gcn10_inflate.hip)
     size_t inflate_ws_cap = 0;
-    // buffers of gcn10_gpu_malloc_spread: one virtual range backed by separately created physical chunks
-    struct Spread {
-        char *va = nullptr;
-        size_t size = 0, chunk = 0;
-        std::vector<hipMemGenericAllocationHandle_t> handles;
-        size_t mapped = 0;          // chunks mapped so far (for unwinding a failed build)
-    };
-    std::vector<Spread> spread;
 };
 
 #endif

@@ -42,7 +42,7 @@ ABI_SYMBOLS = (
     "gcn10_gpu_pci_bus_id", "gcn10_gpu_deflate_fused_strip",
     "gcn10_gpu_deflate_fused_available",
     "gcn10_gpu_inflate_tiles", "gcn10_gpu_stream_copy", "gcn10_gpu_tune_single_raster",
-    "gcn10_gpu_malloc_contiguous", "gcn10_gpu_malloc_spread", "gcn10_gpu_soil_words_state",
+    "gcn10_gpu_soil_words_state",
 )
 
 
@@ -75,8 +75,6 @@ def lib():
             "gcn10_gpu_last_error": (C.c_char_p, []),
             "gcn10_gpu_device_info": (i, [vp, C.c_char_p, sz, C.POINTER(sz)]),
             "gcn10_gpu_malloc": (i, [vp, sz, C.POINTER(vp)]),
-            "gcn10_gpu_malloc_contiguous": (i, [vp, sz, C.POINTER(vp)]),
-            "gcn10_gpu_malloc_spread": (i, [vp, sz, sz, sz, i, C.POINTER(vp)]),
             "gcn10_gpu_free": (i, [vp, vp]),
             "gcn10_gpu_host_alloc": (i, [vp, sz, C.POINTER(vp)]),
             "gcn10_gpu_host_free": (i, [vp, vp]),
@@ -134,24 +132,11 @@ def strip_algorithmic_bytes(W: int, rows: int, hsx: int, hsy: int, cond_mask: in
 class DevBuf:
     """A device allocation made through the C ABI (freed with the engine or on close())."""
 
-    def __init__(self, eng: "Engine", nbytes: int, placement=None):
-        """placement: None (gcn10_gpu_malloc), "contiguous", or ("spread", chunk_bytes, gap_bytes, gap_every)
-        -- see include/gcn10_gpu.h for what the placements are for."""
+    def __init__(self, eng: "Engine", nbytes: int):
         self.eng = eng
         self.nbytes = int(nbytes)
-        self.placement = placement
         p = C.c_void_p()
-        if placement is None:
-            eng._chk(lib().gcn10_gpu_malloc(eng._ctx, self.nbytes, C.byref(p)), "gcn10_gpu_malloc")
-        elif placement == "contiguous":
-            eng._chk(lib().gcn10_gpu_malloc_contiguous(eng._ctx, self.nbytes, C.byref(p)),
-                     "gcn10_gpu_malloc_contiguous")
-        else:
-            kind, chunk, gap, every = placement
-            if kind != "spread":
-                raise ValueError("unknown placement %r" % (placement,))
-            eng._chk(lib().gcn10_gpu_malloc_spread(eng._ctx, self.nbytes, int(chunk), int(gap), int(every),
-                                                   C.byref(p)), "gcn10_gpu_malloc_spread")
+        eng._chk(lib().gcn10_gpu_malloc(eng._ctx, self.nbytes, C.byref(p)), "gcn10_gpu_malloc")
         self.ptr = p.value or 0
         eng._bufs.append(self)
 
@@ -218,20 +203,12 @@ class Engine:
         self._chk(lib().gcn10_gpu_pci_bus_id(self.device, buf, 32), "gcn10_gpu_pci_bus_id")
         return buf.value.decode()
 
-    def alloc(self, nbytes: int, placement=None) -> DevBuf:
-        return DevBuf(self, nbytes, placement)
+    def alloc(self, nbytes: int) -> DevBuf:
+        return DevBuf(self, nbytes)
 
-    def alloc_contiguous(self, nbytes: int) -> DevBuf:
-        """One physically contiguous extent: for rasters that are only read (include/gcn10_gpu.h)."""
-        return DevBuf(self, nbytes, "contiguous")
-
-    def alloc_spread(self, nbytes: int, chunk_bytes: int = 0, gap_bytes: int = 256 << 20, gap_every: int = 1) -> DevBuf:
-        """Physical chunks lying far apart behind one virtual range: for rasters that are only written."""
-        return DevBuf(self, nbytes, ("spread", chunk_bytes, gap_bytes, gap_every))
-
-    def upload(self, arr: np.ndarray, stream=None, placement=None) -> DevBuf:
+    def upload(self, arr: np.ndarray, stream=None) -> DevBuf:
         a = np.ascontiguousarray(arr)
-        buf = DevBuf(self, max(a.nbytes, 1), placement)
+        buf = DevBuf(self, max(a.nbytes, 1))
         self.h2d(buf.ptr, a, stream)
         self.sync(stream)
         return buf

@@ -80,26 +80,6 @@ int gcn10_gpu_pci_bus_id(int device, char *buf, size_t cap);
  * src/raster.c:176-178, 217-219). */
 
 int gcn10_gpu_malloc(gcn10_gpu_ctx *ctx, size_t bytes, void **dptr);
-/* Placement-aware variants (no reference counterpart: a host malloc has no such choice).  On MI355X the rate of a
- * streaming kernel depends on WHERE in VRAM its buffers lie (tools/region_lab.hip,
- * tools/spread_lab.hip): a buffer inside one physically contiguous extent is read fastest and written slowest;
- * a buffer whose pieces lie far apart is written ~12 % faster and read ~5 % slower.  So a raster that is only
- * READ (the landcover block) belongs in a contiguous extent and a raster that is only WRITTEN (a CN raster) in a
- * spread one.  Both return ordinary device pointers, released with gcn10_gpu_free.
- *   _contiguous: one physically contiguous extent (hipDeviceMallocContiguous).
- *   _spread:     one virtual range backed by physical chunks of `chunk_bytes` (rounded up to the device's
- *                mapping granularity; 0 = 32 MiB) created one by one, with `gap_bytes` of ballast allocated after
- *                every `gap_every` chunks (0 = 1) and released again before the call returns, so that consecutive
- *                chunks come from places `gap_bytes` apart.  gap_bytes = 0 builds the range without ballast.
- *                gap_every = -1: TWO POOLS -- the first half of the chunks, one ballast of gap_bytes, the
- *                second half; the range then takes its chunks from the two pools alternately (VRAM comes in
- *                two classes of region that alternate every ~16 GiB of allocation order; a raster that mixes
- *                both is written fastest).
- *                Ballast the device cannot supply is skipped, not an error.  GCN10_E_HIP when the device has no
- *                virtual memory management. */
-int gcn10_gpu_malloc_contiguous(gcn10_gpu_ctx *ctx, size_t bytes, void **dptr);
-int gcn10_gpu_malloc_spread(gcn10_gpu_ctx *ctx, size_t bytes, size_t chunk_bytes, size_t gap_bytes, int gap_every,
-                            void **dptr);
 int gcn10_gpu_free(gcn10_gpu_ctx *ctx, void *dptr);
 int gcn10_gpu_host_alloc(gcn10_gpu_ctx *ctx, size_t bytes, void **hptr);
 int gcn10_gpu_host_free(gcn10_gpu_ctx *ctx, void *hptr);

@@ -218,12 +218,6 @@ int gcn10_gpu_pci_bus_id(int device, char *buf, size_t cap)
 
 int gcn10_gpu_malloc(gcn10_gpu_ctx *c, size_t n, void **p) { (void)c; *p = malloc(n ? n : 1); return *p ? GCN10_OK : GCN10_E_NOMEM; }
 int gcn10_gpu_soil_words_state(gcn10_gpu_ctx *c, gcn10_stream_t s) { (void)c; (void)s; return 0; }
-int gcn10_gpu_malloc_contiguous(gcn10_gpu_ctx *c, size_t n, void **p) { return gcn10_gpu_malloc(c, n, p); }
-int gcn10_gpu_malloc_spread(gcn10_gpu_ctx *c, size_t n, size_t chunk, size_t gap, int every, void **p)
-{
-    (void)chunk; (void)gap; (void)every;
-    return gcn10_gpu_malloc(c, n, p);
-}
 int gcn10_gpu_free(gcn10_gpu_ctx *c, void *p) { (void)c; free(p); return GCN10_OK; }
 int gcn10_gpu_host_alloc(gcn10_gpu_ctx *c, size_t n, void **p) { (void)c; *p = malloc(n ? n : 1); return *p ? GCN10_OK : GCN10_E_NOMEM; }
 int gcn10_gpu_host_free(gcn10_gpu_ctx *c, void *p) { (void)c; free(p); return GCN10_OK; }

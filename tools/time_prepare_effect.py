@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The single-raster strip kernel on BASELINE config 2 with and without gcn10_gpu_prepare_tile in front of every
-launch (is the strip kernel slower right after the soil codes were rewritten?), plain and spread raster, interleaved
+launch (is the strip kernel slower right after the soil codes were rewritten?), compact soil words on and off, interleaved
 rounds.  (GPU only.)"""
 import json
 import os
@@ -20,7 +20,7 @@ esa, gt, coarse, soil_gt = bench.synth_block(1, size, "iid")
 hs = coarse.shape[0]
 ci, cj = host.build_index_maps(gt, soil_gt, size, size, hs, hs)
 d_esa, d_coarse, d_ci, d_cj = eng.upload(esa), eng.upload(coarse), eng.upload(ci), eng.upload(cj)
-outs = {"plain": eng.alloc(npix), "spread": eng.alloc_spread(npix, 32 << 20, 256 << 20, 1)}
+outs = {"plain": eng.alloc(npix), "plain 2": eng.alloc(npix)}
 eng.prepare_tile(d_coarse.ptr, hs, hs, d_ci.ptr, size)
 ev = [(eng.event_create(), eng.event_create()) for _ in range(5)]
 variants = [("flat ilp2 pf bpc8", dict(ilp1=2, prefetch=1, grid_blocks_per_cu=8)),
