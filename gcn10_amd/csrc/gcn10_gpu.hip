@@ -561,7 +561,10 @@ __global__ __launch_bounds__(kThreads) void cn_strip_bytes(const StripParams p,
 // word with the generation they were launched for and use the bytes for the
 // whole tile when it matches.
 // ------------------------------------------------------------------------
-constexpr uint32_t kExpandRows = 2;     // coarse rows per thread of expand_x_codes
+#ifndef GCN10_EXPAND_ROWS
+#define GCN10_EXPAND_ROWS 4     // 2: 20.0 us, 3: 17.3, 4: 16.5, 6: 17.6 for a 36000 x 1440 window (profiles/r02/prepare_tile_rows_per_thread.txt)
+#endif
+constexpr uint32_t kExpandRows = GCN10_EXPAND_ROWS;     // coarse rows per thread of expand_x_codes
 
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void expand_x_codes(const uint8_t *coarse,
