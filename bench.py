@@ -24,6 +24,15 @@ common to the processes of one node).  At N > 1 every rank owns its own block on
 so ranks meet only at a barrier before and after the timed steps, through files
 (gcn10_amd/shard.py) -- no RCCL, no torch.  `python bench.py --gpus N` without a launcher starts
 the N rank processes itself, before anything touches a GPU.
+
+Before the timed region (all of it untimed set-up, recorded in the JSON line): the placement calibration
+of the one-raster workload (roofline.placement: 24 candidate rasters held together, positions and launch
+shapes inside each, three placements of the landcover; --no-tune skips it), --pre-warm-ms of the same
+step (config.pre_warm_steps_untimed: the card's launch times settle only after some tens of
+milliseconds of load), then the W warm-up steps, a barrier, and the K timed steps.
+Environment: GCN10_BENCH_AB=1 adds `ab_prepare_tile` (per-step kernel times of the timed region; the same
+launch with and without gcn10_gpu_prepare_tile in front, measured afterwards); GCN10_BENCH_ENGINE names a
+stand-in engine class for the launcher tests; GCN10_BENCH_OVERSUBSCRIBE=1 = --oversubscribe.
 """
 from __future__ import annotations
 
