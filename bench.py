@@ -260,6 +260,8 @@ def main(argv=None):
                     help="candidate allocations the calibration chooses the raster buffer from")
     ap.add_argument("--tune-sources", type=int, default=3,
                     help="placements of the landcover block the calibration chooses from")
+    ap.add_argument("--no-self-check", action="store_true",
+                    help="skip the comparison of the timed raster with a second variant's (untimed, after the measurement)")
     ap.add_argument("--pre-warm-ms", type=float, default=150.0,
                     help="untimed steps run for this long before the W warm-up steps (clock ramp after the set-up)")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -537,6 +539,42 @@ def main(argv=None):
         copy = dict(_stats(ms), kernel="stream_copy_kernel", bytes_per_launch=2 * nb,
                     achieved_GBps=round(gbs, 1), frac_of_peak=round(gbs / HBM_PEAK_GBS, 4))
 
+    # Self-check (untimed, no oracle involved): the raster the timed launches wrote, against the same strip
+    # computed once more by the most different variant the library has -- soil code BYTES instead of compact
+    # words, one chunk per trip, no software pipeline, plain stores -- into another buffer.  A difference ends
+    # the run: a fast kernel whose result depends on its launch shape is not a result.
+    self_check = None
+    if (not preresampled and not fake_engine and n_out == 1 and strip >= rows_mine and not args.no_self_check
+            and hasattr(eng, "soil_words_state")):
+        other = eng.alloc(npix)
+        eng.memset(other.ptr, 0xEE, npix)
+        words_state = None
+        try:
+            eng.prepare_tile(d_coarse.ptr, hs, hs, d_ci.ptr, size)
+            words_state = eng.soil_words_state()
+            eng.cn_strip(d_esa.ptr, size, rows_mine, d_cj.ptr, cond_mask, table_mask, list(outs))   # the timed variant
+            eng.sync()
+            for name, v in (("compact_soil", 0), ("ilp1", 1), ("prefetch", 0), ("nontemporal", 0)):
+                eng.set_option(name, v)
+            ptrs2 = [other.ptr if p else None for p in outs]
+            eng.cn_strip(d_esa.ptr, size, rows_mine, d_cj.ptr, cond_mask, table_mask, ptrs2)
+            eng.sync()
+            k2 = eng.last_kernel_name()
+        finally:
+            eng.set_option("defaults", 0)
+        differing = 0
+        piece = 1 << 28
+        for o in range(0, npix, piece):
+            n = min(piece, npix - o)
+            differing += int(np.count_nonzero(eng.download(out0 + o, (n,)) != eng.download(other.ptr + o, (n,))))
+        other.close()
+        if differing:
+            raise SystemExit("bench.py: SELF-CHECK FAILED: %d of %d pixels differ between %s and %s" %
+                             (differing, npix, kname, k2))
+        self_check = {"pixels_compared": npix, "differing": 0, "timed_kernel": kname, "against": k2 +
+                      ", soil code bytes, plain stores", "soil_words_state_of_the_timed_tile": words_state}
+        # (the calibrated launch shape was dropped by the options above: nothing below uses the one-raster kernel)
+
     also = None
     if want_also:
         # the product's per-block pass (18 rasters fused), outside the timed region, two ways:
@@ -626,6 +664,8 @@ def main(argv=None):
             "cpu_baseline": cpu,
             "per_rank": ranks,
         }
+        if self_check:
+            line["self_check"] = self_check
         if b2b:
             line["ab_prepare_tile"] = b2b
         if also:
