@@ -29,6 +29,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
@@ -1231,6 +1232,20 @@ int gcn10_run(const gcn10_run_options *opt)
                  r->gpu_deflate ? (r->fused ? ", fused gpu deflate" : ", gpu deflate") : ", host zlib",
                  r->gpu_inflate ? ", gpu inflate of deflate landcover" : "", busy, rd, gw, sw, so, cr, fi, dv);
         gcn10_log_message(log0, "INFO", msg, false);
+        {
+            /* CPU seconds of the whole process (all threads): against the wall time this says whether the host
+             * side is what bounds the run (a cgroup CPU quota shows as user + system ~ quota x wall) */
+            struct rusage ru;
+
+            if (getrusage(RUSAGE_SELF, &ru) == 0) {
+                snprintf(msg, sizeof msg, "timing: host cpu seconds: user %.3f, system %.3f, over %.3f s wall; "
+                         "voluntary / involuntary context switches %ld / %ld",
+                         (double)ru.ru_utime.tv_sec + ru.ru_utime.tv_usec * 1e-6,
+                         (double)ru.ru_stime.tv_sec + ru.ru_stime.tv_usec * 1e-6, now_seconds() - t_start,
+                         ru.ru_nvcsw, ru.ru_nivcsw);
+                gcn10_log_message(log0, "INFO", msg, false);
+            }
+        }
         /* one line per GPU: when a node's GPUs are not equally busy, these tell a slow device or PCIe
          * root complex (waiting for gpu) from a slow NUMA node or file system (reading, waiting for sink) */
         for (int d = 0; d < r->n_devices; d++) {
