@@ -160,7 +160,12 @@ int gcn10_gpu_calculate_cn(gcn10_gpu_ctx *ctx, const uint8_t *esa,
  * out[] has GCN10_N_RASTERS entries (host array of device pointers); entries
  * of unselected rasters are ignored and may be NULL.  Strips of one block may
  * be issued on different streams once prepare_tile's stream work is ordered
- * before them (event or sync). */
+ * before them (event or sync).
+ * out[] must point into ordinary device allocations (gcn10_gpu_malloc / hipMalloc).
+ * Ranges assembled with HIP's virtual memory management (hipMemCreate + hipMemMap)
+ * are not supported: the kernels store nontemporally, and such stores into chunk-
+ * mapped ranges were observed not to be visible yet when the kernel had completed
+ * (ROCm 7.2, MI355X; profiles/r02/spread_allocator_hazard.txt). */
 int gcn10_gpu_prepare_tile(gcn10_gpu_ctx *ctx, const uint8_t *coarse, int hsx,
                            int hsy, const int32_t *ci, int W,
                            gcn10_stream_t stream);
