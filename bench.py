@@ -327,6 +327,7 @@ def main(argv=None):
     outs = [None] * 18
     out_bufs = []
     placement = None
+    spare_rasters = []      # candidates of the calibration kept for the config-4 leg
     # (A/B switch: allocating the 17 extra rasters of the config4 leg BEFORE the calibration's candidates put
     # every candidate in a slow place in both processes that tried it -- 0.484 ms against 0.438-0.465 ms,
     # profiles/r02/bench_alloc_order_ab.txt -- so they are allocated after it)
@@ -372,9 +373,14 @@ def main(argv=None):
                                                           c.ptr, npix + slack, 16 << 20)
                         tried.append(round(ms, 4))
                     keep = int(np.argmin(tried))
+                    # the seventeen next-best candidates become the other rasters of the config-4 leg (they
+                    # are written, never read: what the calibration timed is what that kernel does to them)
+                    order = [i for i in np.argsort(tried) if i != keep]
+                    keep_extra = set(order[:17]) if want_also else set()
                     for i, c in enumerate(cands):
-                        if i != keep:
+                        if i != keep and i not in keep_extra:
                             c.close()
+                    spare_rasters = [cands[i] for i in order[:17] if i in keep_extra]
                     for sp in spacers:
                         sp.close()
                     b = cands[keep]
@@ -413,6 +419,7 @@ def main(argv=None):
                         except Exception:
                             pass
                     out_bufs[:] = [x for x in out_bufs if x not in cands]
+                    spare_rasters = []
                     eng.set_option("defaults", 0)
                     placement = {"error": str(exc)}
                     b = eng.alloc(npix)
@@ -426,7 +433,8 @@ def main(argv=None):
     del esa_host
     if want_also and not extra:
         # the extra config4 measurement writes 18 rasters: allocate the other 17 now, long before they are timed
-        extra = [eng.alloc(npix) for _ in range(17)]
+        extra = list(spare_rasters[:17])
+        extra += [eng.alloc(npix) for _ in range(17 - len(extra))]
     d_fine = None
     if preresampled:
         d_fine = eng.alloc(npix)
