@@ -12,15 +12,20 @@ import numpy as np
 
 
 class _Buf:
+    _count = 0
+
     def __init__(self, n):
-        self.ptr = 0x1000 + n % 4096
+        _Buf._count += 1
+        self.serial = _Buf._count
+        self.ptr = 0x100000000 * self.serial        # distinct, far apart: the stand-in never dereferences them
         self.n = n
+        self.closed = False
 
     def at(self, off):
         return self.ptr + off
 
     def close(self):
-        pass
+        self.closed = True
 
 
 class FakeEngine:
@@ -56,6 +61,20 @@ class FakeEngine:
 
     def resample(self, *a):
         pass
+
+    def set_option(self, name, value):
+        pass
+
+    def tune_single_raster(self, esa, W, rows, cj, cond_mask, table_mask, arena, arena_bytes, step, stream=None):
+        """The calibration entry of the real engine, without launches: a time that depends on the arena only
+        (every fifth allocation is the 'fast' one), the best position a step into it."""
+        serial = arena // 0x100000000
+        ms = 2.0 * self._scale * (0.9 if serial % 5 == 0 else 1.0) + 1e-4 * (serial % 7)
+        positions = max(1, (arena_bytes - W * rows) // step + 1)
+        report = {"positions": int(positions), "step_bytes": int(step), "shapes": 8, "best_ms": round(ms, 4),
+                  "worst_ms": round(ms * 1.1, 4), "best_offset_bytes": int(step), "xcd_slabs": 1,
+                  "grid_blocks_per_cu": 8, "ilp1": 2, "prefetch": 1}
+        return arena + step, ms, report
 
     def calculate_cn(self, *a):
         self._launch()

@@ -170,6 +170,24 @@ def test_bench_single_rank_with_the_stand_in_engine():
     assert rec["also"]["workload"].startswith("config4") and "round1_style_ms_per_launch" in rec["also"]
 
 
+def test_bench_calibration_code_path_with_the_stand_in_engine():
+    """The placement calibration of bench.py (candidates held together, spacers, the winner tuned once more,
+    landcover placements, next-best candidates handed to the config-4 leg) runs through on the stand-in engine."""
+    out = _bench(["--steps", "3", "--warmup", "1", "--size", "2048", "--no-cpu-baseline", "--tune-arenas", "7"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "calibration skipped" not in out.stderr
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    pl = rec["roofline"]["placement"]
+    assert len(pl["allocations_tried_best_ms"]) == 7 and len(pl["landcover_placements_tried_best_ms"]) == 3
+    assert pl["best_ms"] == min(pl["allocations_tried_best_ms"])            # the 'fast' arena of the stand-in won
+    assert rec["also"]["workload"].startswith("config4")
+    # and switched off
+    out = _bench(["--steps", "2", "--warmup", "0", "--size", "2048", "--no-cpu-baseline", "--no-tune"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["roofline"]["placement"] is None
+
+
 def test_bench_strong_scaling_splits_one_block_into_row_bands():
     """--scaling strong: SURVEY 8(e) "within a single huge tile, split by row ranges across GPUs"."""
     out = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "2050", "--no-cpu-baseline",
