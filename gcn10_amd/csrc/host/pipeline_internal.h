@@ -12,7 +12,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-enum { TILE = 256, MAX_NBUF = 4, DEFAULT_NBUF = 3, DEFAULT_STRIP_ROWS = 768, MAX_STRIP_ROWS = 4096 };
+enum { TILE = 256, MAX_NBUF = 8, DEFAULT_NBUF = 4, DEFAULT_STRIP_ROWS = 768, MAX_STRIP_ROWS = 4096 };
 
 struct run;
 
@@ -100,7 +100,7 @@ struct run {
     atomic_int next_block;
     atomic_int fatal;                       /* a worker hit an MPI_Abort-class error */
     int strip_rows;                         /* "strip_rows" of the config, rounded up to whole tile rows */
-    int nbuf;                               /* strip buffer sets per worker (GCN10_STRIP_BUFFERS, 2..4) */
+    int nbuf;                               /* strip buffer sets per worker (GCN10_STRIP_BUFFERS, 2..8) */
     int deflate_level;
     bool null_sink;                         /* GCN10_SINK=null: no compression, no files */
     bool gpu_deflate;                       /* tiles are encoded on the GPU */
