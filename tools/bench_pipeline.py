@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--gpu-deflate", type=int, default=2)
     ap.add_argument("--workers-per-gpu", type=int, default=0)
     ap.add_argument("--gpu-inflate", type=int, default=1)
+    ap.add_argument("--io-threads", type=int, default=0, help='config key "io_threads" (0 = the program\'s choice)')
     ap.add_argument("--lookups", default="", help='config key "lookups" (e.g. g_ii): BASELINE config 3, single lookup')
     ap.add_argument("--conditions", default="", help='config key "conditions" (drained | undrained | both)')
     ap.add_argument("--repeat", type=int, default=1,
@@ -68,9 +69,9 @@ def main():
     with open(os.path.join(wd, "config.txt"), "w") as f:
         f.write("hysogs_data_path=%s/soil.tif\nesa_data_path=%s/esa.tif\nblocks_shp_path=%s/blocks.shp\n"
                 "lookup_table_path=%s\nlog_dir=%s/logs\nstrip_rows=%d\ndeflate_level=%d\ngpu_deflate=%d\n"
-                "workers_per_gpu=%d\ngpu_inflate=%d\n%s%s"
+                "workers_per_gpu=%d\ngpu_inflate=%d\nio_threads=%d\n%s%s"
                 % (wd, wd, wd, os.path.join(ROOT, "tests", "golden", "lookups"), wd, a.strip_rows,
-                   a.deflate_level, a.gpu_deflate, a.workers_per_gpu, a.gpu_inflate,
+                   a.deflate_level, a.gpu_deflate, a.workers_per_gpu, a.gpu_inflate, a.io_threads,
                    "lookups=%s\n" % a.lookups if a.lookups else "", "conditions=%s\n" % a.conditions if a.conditions else ""))
     build_s = time.time() - t0
     run_modes(a, wd, size, nb, build_s)
