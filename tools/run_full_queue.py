@@ -88,7 +88,8 @@ def main():
                 p = os.path.join(work, "cn_rasters_%s" % cond, "cn_%s_%s_%d.tif" % (hc, arc, ids[i]))
                 if not os.path.exists(p) or not np.array_equal(np.array(Image.open(p)), want[r]):
                     bad += 1
-        timing = re.findall(r"timing: .*", logs)
+        timing = re.findall(r"timing: \d+ blocks.*", logs)
+        host_cpu = re.findall(r"timing: host cpu seconds.*", logs)
         rec["runs"].append({
             "what": name, "rc": out.returncode, "wall_s": round(wall, 2),
             "log_says_processing": bool(re.search(r"processing %d blocks from shapefile" % len(ids), logs)),
@@ -98,6 +99,7 @@ def main():
             "files": n_files, "files_expected": len(ids) * n_out,
             "sampled_blocks": int(a.samples), "sampled_rasters_differing_from_oracle": bad,
             "timing_line": timing[-1][:600] if timing else None,
+            "host_cpu_line": host_cpu[-1][:300] if host_cpu else None,
             "stderr_tail": out.stderr[-300:] if out.returncode else ""})
     ok = all(r["rc"] == 0 and r["every_id_exactly_n_rasters_once"] and r["files"] == r["files_expected"]
              and r["sampled_rasters_differing_from_oracle"] == 0 and r["log_says_processed"] for r in rec["runs"])
