@@ -124,8 +124,12 @@ def cpu_baseline(workload: str, size: int):
         "sample": "%d independent worker processes (as mpirun -n %d, src/main.c:171), each %d rows x %d px of "
                   "the synthetic block, %d CN raster(s), oracle_process_block_subset (src/cn.c:218-290 "
                   "loop structure, per-raster malloc/memcpy/memset, I/O excluded), gcc -O3 no -march; "
-                  "slowest worker %.1f s" % (head["procs"], head["procs"], head["rows_per_proc"], size, n_out,
-                                             head["worker_seconds_max"]),
+                  "slowest worker %.1f s; %s" % (head["procs"], head["procs"], head["rows_per_proc"], size, n_out,
+                                                 head["worker_seconds_max"],
+                                                 ("the box's cgroup CPU quota is %s CPUs: runs with more workers than "
+                                                  "that (see `runs`) share the same quota and are not faster"
+                                                  % r.get("cpu_quota_cores")) if r.get("cpu_quota_cores")
+                                                 else "no cgroup CPU quota found"),
         "runs": r["runs"],                              # P = 1, the 16-core share, all physical cores
         "best_cpu": r.get("best_cpu"),                  # fused single pass, -O3 -march=native, all physical cores
         "single_core_value": round(r["runs"][0]["gpx_per_s"], 4),
@@ -150,12 +154,14 @@ def _host_cpu():
     return {"model": model, "sockets": len(sockets) or None}
 
 
-def traffic_from_profiles(workload: str):
-    """HBM bytes per launch from the committed PMC pass (profiles/pmc_traffic.json), or None."""
+def traffic_from_profiles(workload: str, field: str = "hbm_bytes_per_launch"):
+    """HBM bytes per launch from the committed PMC pass (profiles/pmc_traffic.json), or None.
+    field="kernel": the kernel instantiation that pass measured (it is the launch shape the calibration
+    chose on the profiling box, not necessarily the one this run times)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         rec = json.load(open(path)).get(workload)
-        return rec["hbm_bytes_per_launch"] if rec else None
+        return rec.get(field) if rec else None
     except Exception:
         return None
 
@@ -511,6 +517,42 @@ def main(argv=None):
         eng.sync()
         return [eng.elapsed_ms(a, b) for a, b in ev[:n]]
 
+    # Self-check (untimed, no oracle involved; straight after the timed region, before any other leg writes
+    # into the raster): the bytes the timed launches left in the raster, against the same strip
+    # computed once more by the most different variant the library has -- soil code BYTES instead of compact
+    # words, one chunk per trip, no software pipeline, plain stores -- into another buffer.  A difference ends
+    # the run: a fast kernel whose result depends on its launch shape is not a result.
+    self_check = None
+    if (not preresampled and not fake_engine and n_out == 1 and strip >= rows_mine and not args.no_self_check
+            and hasattr(eng, "soil_words_state")):
+        other = eng.alloc(npix)
+        eng.memset(other.ptr, 0xEE, npix)
+        words_state = None
+        try:
+            # out0 holds what the LAST TIMED launch wrote: nothing has touched it since the timed region
+            words_state = eng.soil_words_state()
+            for name, v in (("compact_soil", 0), ("ilp1", 1), ("prefetch", 0), ("nontemporal", 0)):
+                eng.set_option(name, v)
+            ptrs2 = [other.ptr if p else None for p in outs]
+            eng.cn_strip(d_esa.ptr, size, rows_mine, d_cj.ptr, cond_mask, table_mask, ptrs2)
+            eng.sync()
+            k2 = eng.last_kernel_name()
+        finally:
+            eng.set_option("defaults", 0)
+        differing = 0
+        piece = 1 << 28
+        for o in range(0, npix, piece):
+            n = min(piece, npix - o)
+            differing += int(np.count_nonzero(eng.download(out0 + o, (n,)) != eng.download(other.ptr + o, (n,))))
+        other.close()
+        if differing:
+            raise SystemExit("bench.py: SELF-CHECK FAILED: %d of %d pixels differ between %s and %s" %
+                             (differing, npix, kname, k2))
+        self_check = {"pixels_compared": npix, "differing": 0, "timed_kernel": kname, "against": k2 +
+                      ", soil code bytes, plain stores", "soil_words_state_of_the_timed_tile": words_state}
+        # (the calibrated launch shape was dropped by the options above: nothing below uses the one-raster kernel)
+        self_check["checked"] = "the raster as the last timed launch left it (no re-launch of the timed variant)"
+
     # diagnostic (GCN10_BENCH_AB=1): the same strip launch back to back, without gcn10_gpu_prepare_tile in between
     b2b = None
     if os.environ.get("GCN10_BENCH_AB") == "1" and not preresampled and strip >= rows_mine:
@@ -542,46 +584,10 @@ def main(argv=None):
     copy = None
     if not args.no_also and not preresampled and hasattr(eng, "stream_copy"):
         nb = npix - npix % 16
-        ms = timed_launches(lambda: eng.stream_copy(d_esa.ptr, out0, nb))
+        ms = timed_launches(lambda: eng.stream_copy(d_esa.ptr, out0, nb), warm=40)
         gbs = 2 * nb / float(np.mean(ms)) / 1e6
         copy = dict(_stats(ms), kernel="stream_copy_kernel", bytes_per_launch=2 * nb,
                     achieved_GBps=round(gbs, 1), frac_of_peak=round(gbs / HBM_PEAK_GBS, 4))
-
-    # Self-check (untimed, no oracle involved): the raster the timed launches wrote, against the same strip
-    # computed once more by the most different variant the library has -- soil code BYTES instead of compact
-    # words, one chunk per trip, no software pipeline, plain stores -- into another buffer.  A difference ends
-    # the run: a fast kernel whose result depends on its launch shape is not a result.
-    self_check = None
-    if (not preresampled and not fake_engine and n_out == 1 and strip >= rows_mine and not args.no_self_check
-            and hasattr(eng, "soil_words_state")):
-        other = eng.alloc(npix)
-        eng.memset(other.ptr, 0xEE, npix)
-        words_state = None
-        try:
-            eng.prepare_tile(d_coarse.ptr, hs, hs, d_ci.ptr, size)
-            words_state = eng.soil_words_state()
-            eng.cn_strip(d_esa.ptr, size, rows_mine, d_cj.ptr, cond_mask, table_mask, list(outs))   # the timed variant
-            eng.sync()
-            for name, v in (("compact_soil", 0), ("ilp1", 1), ("prefetch", 0), ("nontemporal", 0)):
-                eng.set_option(name, v)
-            ptrs2 = [other.ptr if p else None for p in outs]
-            eng.cn_strip(d_esa.ptr, size, rows_mine, d_cj.ptr, cond_mask, table_mask, ptrs2)
-            eng.sync()
-            k2 = eng.last_kernel_name()
-        finally:
-            eng.set_option("defaults", 0)
-        differing = 0
-        piece = 1 << 28
-        for o in range(0, npix, piece):
-            n = min(piece, npix - o)
-            differing += int(np.count_nonzero(eng.download(out0 + o, (n,)) != eng.download(other.ptr + o, (n,))))
-        other.close()
-        if differing:
-            raise SystemExit("bench.py: SELF-CHECK FAILED: %d of %d pixels differ between %s and %s" %
-                             (differing, npix, kname, k2))
-        self_check = {"pixels_compared": npix, "differing": 0, "timed_kernel": kname, "against": k2 +
-                      ", soil code bytes, plain stores", "soil_words_state_of_the_timed_tile": words_state}
-        # (the calibrated launch shape was dropped by the options above: nothing below uses the one-raster kernel)
 
     also = None
     if want_also:
@@ -627,6 +633,13 @@ def main(argv=None):
             for b in extra:
                 b.close()
 
+    uncalibrated_frac = None
+    try:
+        tried_ms = (placement or {}).get("allocations_tried_best_ms") if isinstance(placement, dict) else None
+        if tried_ms:
+            uncalibrated_frac = round(alg_bytes / (float(np.median(tried_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    except Exception:
+        uncalibrated_frac = None
     mine = {"rank": rank, "device": device, "pci_bus_id": bus, "numa_node": numa, "cpus_bound": bound,
             "t_start": t_start, "t_end": t_end, "elapsed_s": round(t_end - t_start, 6),
             "kernel_avg_ms": round(avg_launch_s * 1e3, 4), "kernel": kname, "rows": [band[0], band[1]],
@@ -662,6 +675,12 @@ def main(argv=None):
                          # the committed PMC passes were taken at the default shape only
                          "traffic": traffic_from_profiles(args.workload)
                          if (size == 36000 and strip == size and args.pattern == "iid") else None,
+                         "traffic_kernel": traffic_from_profiles(args.workload, "kernel")
+                         if (size == 36000 and strip == size and args.pattern == "iid") else None,
+                         "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes, not this run)",
+                         # what ONE ordinary allocation gets: the median over the candidate rasters the untimed
+                         # calibration tried (bin/gcn10 does not calibrate: it never writes a raster to HBM)
+                         "uncalibrated_frac": uncalibrated_frac,
                          "kernel": kname, "algorithmic_bytes_per_launch": int(alg_bytes),
                          "avg_launch_ms": round(avg_launch_s * 1e3, 4),
                          "median_launch_ms": round(float(np.median(kernel_ms)) / launches, 4),

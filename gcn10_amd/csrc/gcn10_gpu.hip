@@ -597,8 +597,10 @@ __global__ __launch_bounds__(kThreads) void expand_x_codes(const uint8_t *coarse
         for (int q = 0; q < 16; q++) {
             // columns past W are padding: marked here, given the "invalid" code below
             const uint32_t xx = x + q;
-            const uint32_t c = xx < W ? (uint32_t)ci[xx] : 0xffffffffu;
-            cx[q] = c == 0xffffffffu ? c : (c < hsx ? c : hsx - 1u);
+            // (an index of the raster is clamped exactly as in the vector path, whatever its value;
+            // only columns past W get the padding mark)
+            const uint32_t c = xx < W ? (uint32_t)ci[xx] : 0u;
+            cx[q] = xx < W ? (c < hsx ? c : hsx - 1u) : 0xffffffffu;
         }
     }
     // at the usual ratio (25 fine columns per coarse cell) 16 consecutive columns see at most two coarse
@@ -805,26 +807,26 @@ strip_kernel_t pick_by_mask2(unsigned cond_mask, bool all)
     }
 }
 
-bool g_prefetch = true;     // set per launch by pick_strip_kernel
-
+// (the pipeline choice `pf` is an argument all the way down: two worker threads pick kernels for their
+// own contexts at the same time, a process-wide flag would be a data race)
 template <int KIND, int ILP, bool NT>
-strip_kernel_t pick_by_mask(unsigned cond_mask, bool all)
+strip_kernel_t pick_by_mask(unsigned cond_mask, bool all, bool pf)
 {
     // pipelined variants exist for ILP 1 and 2 (two register sets of ILP 4 cost occupancy)
-    if (ILP <= 2 && g_prefetch)
+    if (ILP <= 2 && pf)
         return pick_by_mask2<KIND, (ILP <= 2 ? ILP : 1), NT, true>(cond_mask, all);
     return pick_by_mask2<KIND, ILP, NT, false>(cond_mask, all);
 }
 
 template <int KIND>
-strip_kernel_t pick_by_ilp(unsigned cond_mask, bool all, int ilp, bool nt)
+strip_kernel_t pick_by_ilp(unsigned cond_mask, bool all, int ilp, bool nt, bool pf)
 {
     switch (ilp) {
-    case 1: return nt ? pick_by_mask<KIND, 1, true>(cond_mask, all) : pick_by_mask<KIND, 1, false>(cond_mask, all);
-    case 2: return nt ? pick_by_mask<KIND, 2, true>(cond_mask, all) : pick_by_mask<KIND, 2, false>(cond_mask, all);
+    case 1: return nt ? pick_by_mask<KIND, 1, true>(cond_mask, all, pf) : pick_by_mask<KIND, 1, false>(cond_mask, all, pf);
+    case 2: return nt ? pick_by_mask<KIND, 2, true>(cond_mask, all, pf) : pick_by_mask<KIND, 2, false>(cond_mask, all, pf);
     case 4:
         if (KIND == kLut1)
-            return nt ? pick_by_mask<kLut1, 4, true>(cond_mask, all) : pick_by_mask<kLut1, 4, false>(cond_mask, all);
+            return nt ? pick_by_mask<kLut1, 4, true>(cond_mask, all, pf) : pick_by_mask<kLut1, 4, false>(cond_mask, all, pf);
         return nullptr;
     default: return nullptr;
     }
@@ -832,9 +834,8 @@ strip_kernel_t pick_by_ilp(unsigned cond_mask, bool all, int ilp, bool nt)
 
 strip_kernel_t pick_strip_kernel(bool single, unsigned cond_mask, bool all, int ilp, bool nt, bool pf)
 {
-    g_prefetch = pf;
-    return single ? pick_by_ilp<kLut1>(cond_mask, all, ilp, nt)
-                  : pick_by_ilp<kLut16>(cond_mask, all, ilp, nt);
+    return single ? pick_by_ilp<kLut1>(cond_mask, all, ilp, nt, pf)
+                  : pick_by_ilp<kLut16>(cond_mask, all, ilp, nt, pf);
 }
 
 }  // namespace
@@ -1378,7 +1379,8 @@ int gcn10_gpu_prepare_tile(gcn10_gpu_ctx *ctx, const uint8_t *coarse, int hsx, i
         ctx->d_hx = ctx->d_hx_alloc + 16;
         ctx->d_hx4 = reinterpret_cast<uint32_t *>(ctx->d_hx + need16);
         ctx->d_hx4_complex = reinterpret_cast<uint32_t *>(ctx->d_hx + need16 + need16 / 4);
-        HIP_TRY(hipMemset(ctx->d_hx4_complex, 0, 4));
+        // on the launch's own stream: ordered before expand_x_codes whatever the blocking mode of the stream
+        HIP_TRY(hipMemsetAsync(ctx->d_hx4_complex, 0, 4, as_stream(ctx, stream)));
         ctx->hx4_gen = 0;
         ctx->hx_capacity = need;
     }

@@ -56,8 +56,12 @@ def default_rendezvous_dir() -> str:
         return d
     ppid = os.getppid()
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
-    return os.path.join(base, "gcn10_rdv_%d_%d_%s_%s" % (os.getuid(), ppid, _proc_start_ticks(ppid),
-                                                          os.environ.get("MASTER_PORT", "0")))
+    # an elastic agent that restarts its workers keeps its pid: the run id and the restart count keep a new
+    # attempt out of the previous attempt's directory (whose s000000_r*.json files would complete its barriers)
+    attempt = "%s_%s" % (os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
+    attempt = "".join(c if c.isalnum() or c in "-_" else "_" for c in attempt)[:64]
+    return os.path.join(base, "gcn10_rdv_%d_%d_%s_%s_%s" % (os.getuid(), ppid, _proc_start_ticks(ppid),
+                                                             os.environ.get("MASTER_PORT", "0"), attempt))
 
 
 class SoloGroup:
@@ -105,6 +109,14 @@ class FileGroup:
         self._seq = 0
         self._closed = False
         os.makedirs(self.dir, exist_ok=True)
+        # a directory that already holds THIS rank's files belongs to an earlier attempt: they would let the
+        # other ranks' barriers complete on stale data
+        for name in os.listdir(self.dir):
+            if name.endswith("_r%d.json" % rank) or name == "fin_r%d" % rank:
+                try:
+                    os.unlink(os.path.join(self.dir, name))
+                except OSError:
+                    pass
 
     def _path(self, seq: int, rank: int) -> str:
         return os.path.join(self.dir, "s%06d_r%d.json" % (seq, rank))
@@ -213,6 +225,12 @@ def Group(backend: Optional[str] = None, device_index: Optional[int] = None):
         return SoloGroup()
     backend = backend or os.environ.get("GCN10_DIST_BACKEND") or "file"
     if backend == "file":
+        # the file rendezvous is node-local: a job that spans nodes would wait out the time-out instead
+        local_world = os.environ.get("LOCAL_WORLD_SIZE")
+        if local_world and int(local_world) != world and not os.environ.get("GCN10_RDV_DIR"):
+            raise RuntimeError("WORLD_SIZE %d != LOCAL_WORLD_SIZE %s: the default file rendezvous works on one node "
+                               "only; set GCN10_DIST_BACKEND=gloo (or nccl), or GCN10_RDV_DIR to a directory all "
+                               "nodes share" % (world, local_world))
         return FileGroup(rank, world, local_rank=local_rank)
     if backend in ("gloo", "nccl"):
         return TorchGroup(backend, device_index)

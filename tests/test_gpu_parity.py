@@ -440,3 +440,46 @@ def test_full_size_strips_and_single_table_kernels_agree(eng9, full_tile):
         assert np.array_equal(a, b)
     tmp.close()
     e.stream_destroy(s)
+
+
+def test_full_size_nontemporal_and_plain_stores_write_the_same_bytes(eng9, full_tile):
+    """Pins the default store policy: a full-size raster written into a plain device
+    allocation with nontemporal stores (the default of every product raster) and once more with plain stores,
+    both read back right after the writer's stream has been synchronised, every byte compared -- for the
+    single-raster kernel and for the 18-raster kernel (raster 0 of it).  A store that was not yet visible when
+    the kernel had completed (the hazard seen with chunk-mapped ranges in round 2,
+    profiles/r02/spread_allocator_hazard.txt) would leave the 0x5A / 0xA5 fill behind."""
+    ft = full_tile
+    H, W = ft["H"], ft["W"]
+    e = eng9
+    nt, plain = e.alloc(H * W), e.alloc(H * W)
+    try:
+        for kind in ("single", "all18"):
+            e.memset(nt.ptr, 0x5A, H * W)
+            e.memset(plain.ptr, 0xA5, H * W)
+            e.sync()
+            for buf, policy in ((nt, 1), (plain, 0)):
+                e.set_option("nontemporal", policy)
+                e.prepare_tile(ft["bufs"]["coarse"].ptr, 1440, 1440, ft["bufs"]["ci"].ptr, W)
+                if kind == "single":
+                    ptrs = [None] * 18
+                    ptrs[9 + 4] = buf.ptr
+                    e.cn_strip(ft["bufs"]["esa"].ptr, W, H, ft["bufs"]["cj"].ptr, 2, 1 << 4, ptrs)
+                else:
+                    # the other 17 rasters of the launch go where the fixture's rasters are (same bytes again)
+                    ptrs = [o.ptr for o in ft["outs"]]
+                    ptrs[0] = buf.ptr
+                    e.cn_strip(ft["bufs"]["esa"].ptr, W, H, ft["bufs"]["cj"].ptr, 3, 0x1FF, ptrs)
+                e.sync()
+            ref = ft["outs"][9 + 4 if kind == "single" else 0]
+            a = e.download(nt.ptr, (H * W,))
+            b = e.download(plain.ptr, (H * W,))
+            c = e.download(ref.ptr, (H * W,))
+            assert np.array_equal(a, b), "%s: nontemporal and plain stores differ in %d bytes" % (
+                kind, int(np.count_nonzero(a != b)))
+            assert np.array_equal(a, c), kind
+            del a, b, c
+    finally:
+        e.set_option("defaults", 0)
+        nt.close()
+        plain.close()

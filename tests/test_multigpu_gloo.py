@@ -100,6 +100,35 @@ def test_file_group_times_out_when_a_rank_is_missing(tmp_path):
         g.barrier()
 
 
+def test_file_group_refuses_a_job_that_spans_nodes(monkeypatch):
+    """the default (node-local) file rendezvous fails at once, instead of timing out after
+    600 s, when torchrun says the job has more ranks than this node holds."""
+    for k, v in (("RANK", "1"), ("LOCAL_RANK", "1"), ("WORLD_SIZE", "4"), ("LOCAL_WORLD_SIZE", "2")):
+        monkeypatch.setenv(k, v)
+    monkeypatch.delenv("GCN10_RDV_DIR", raising=False)
+    monkeypatch.delenv("GCN10_DIST_BACKEND", raising=False)
+    with pytest.raises(RuntimeError, match="one node"):
+        shard.Group()
+
+
+def test_file_group_ignores_an_earlier_attempts_files(tmp_path, monkeypatch):
+    """Workers restarted by the same elastic agent: the directory name carries the restart count, and a rank
+    clears its own stale files when it joins a directory that already exists."""
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job/7")
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "0")
+    monkeypatch.delenv("GCN10_RDV_DIR", raising=False)
+    first = shard.default_rendezvous_dir()
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "1")
+    assert shard.default_rendezvous_dir() != first and "/" not in os.path.basename(first)
+    d = tmp_path / "rdv"
+    d.mkdir()
+    (d / "s000000_r0.json").write_text("null")          # what a dead attempt of rank 0 left behind
+    (d / "s000000_r1.json").write_text("null")
+    g = shard.FileGroup(0, 2, directory=str(d), timeout_s=0.3)
+    assert not (d / "s000000_r0.json").exists() and (d / "s000000_r1.json").exists()
+    g._closed = True
+
+
 FAKE = dict(GCN10_BENCH_ENGINE="tests.fake_engine:FakeEngine", GCN10_FAKE_DEVICES="2", GCN10_FAKE_LAUNCH_S="0.004")
 
 
