@@ -53,7 +53,7 @@ asan-host:
 # asynchronous host stub of the GPU library (tests/stub_gpu: test infrastructure, never a fallback);
 # 3 workers x 8 blocks through gcn10_run in three sink modes, rasters compared with the oracle
 tsan-host: oracle host
-	python3 tests/tsan_host.py profiles/r02/tsan_host.log
+	python3 tests/tsan_host.py profiles/r03/tsan_host.log
 
 clean:
 	rm -f $(PKG)/*.so bin/gcn10

@@ -559,13 +559,9 @@ __global__ __launch_bounds__(kBuildThreads) void deflate_codes_kernel(const Tile
     uint32_t bytes = (bits + 7u) / 8u + 4u;
     if (bytes > (uint32_t)kMaxStream - 64u)
         bytes = (uint32_t)kMaxStream;           // stored fallback
-    const unsigned long long need = (bytes + (kSlotAlign - 1)) & ~(unsigned long long)(kSlotAlign - 1);
-    const unsigned long long slot = atomicAdd(job.cursor, need);
-    const bool fits = slot + need <= job.arena_cap;
+    // (its place in the arena: deflate_place_kernel, the next launch)
     book->stream_bytes = bytes;
-    book->slot = fits ? (uint32_t)slot : 0xffffffffu;
-    job.table[(size_t)tile * 2] = fits ? (uint32_t)slot : 0xffffffffu;
-    job.table[(size_t)tile * 2 + 1] = fits ? bytes : 0u;
+    book->slot = 0xffffffffu;
 }
 
 // ------------------------------------------------------------------------
@@ -981,14 +977,108 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
         uint32_t bytes = (bits_total + 7u) / 8u + 4u;
         if (bytes > (uint32_t)kMaxStream - 64u)
             bytes = (uint32_t)kMaxStream;       // stored fallback
-        const unsigned long long need = (bytes + (kSlotAlign - 1)) & ~(unsigned long long)(kSlotAlign - 1);
-        const unsigned long long slot = atomicAdd(job.cursor, need);
-        const bool fits = slot + need <= job.arena_cap;
+        // (its place in the arena: deflate_place_kernel, the next launch)
         book->header_bits = header_bits;
         book->stream_bytes = bytes;
-        book->slot = fits ? (uint32_t)slot : 0xffffffffu;
-        job.table[(size_t)tile * 2] = fits ? (uint32_t)slot : 0xffffffffu;
-        job.table[(size_t)tile * 2 + 1] = fits ? bytes : 0u;
+        book->slot = 0xffffffffu;
+    }
+}
+
+// ------------------------------------------------------------------------
+// pass B': where every stream goes.  One workgroup; streams are laid out in index order
+// (raster-major, tiles of a raster row-major), 16-byte aligned, and every raster's first
+// stream starts at a multiple of `seg_align`: the streams of one raster of a strip are ONE
+// contiguous extent of the arena, in tile order, so the host appends them to the raster's
+// GeoTIFF with a single write (and, with seg_align = 4096, may do so with O_DIRECT straight
+// from the pinned copy of the arena).  Replaces the atomic slot reservation of rounds 1-2,
+// whose order was the order in which the code-construction waves happened to finish.
+// Aliases (fused encoder: this raster's tile is another raster's stream) take no room.
+// *cursor = arena bytes used, pads included; a stream that does not fit gets offset
+// 0xffffffff and size 0, as before.
+// ------------------------------------------------------------------------
+constexpr int kPlaceThreads = 1024;
+
+__device__ __forceinline__ uint32_t place_need(const TileJob &job, uint32_t i)
+{
+    const Book *b = reinterpret_cast<const Book *>(job.books + (size_t)i * kBookBytes);
+    return b->slot == kAliasSlot ? 0u : (b->stream_bytes + (uint32_t)(kSlotAlign - 1)) & ~(uint32_t)(kSlotAlign - 1);
+}
+
+__global__ __launch_bounds__(kPlaceThreads) void deflate_place_kernel(const TileJob job, uint32_t tiles_per_raster,
+                                                                      uint32_t seg_align)
+{
+    __shared__ unsigned long long wave_tot[kPlaceThreads / 64];
+    __shared__ unsigned long long P[GCN10_N_RASTERS + 1];       // unaligned prefix at each raster's first stream
+    __shared__ unsigned long long seg[GCN10_N_RASTERS + 1];     // where each raster's extent starts
+    const uint32_t t = threadIdx.x;
+    const uint32_t n = job.n_tiles;
+    const uint32_t n_rasters = n / tiles_per_raster;
+    const uint32_t K = (n + kPlaceThreads - 1) / kPlaceThreads;
+    const uint32_t i0 = t * K < n ? t * K : n, i1 = i0 + K < n ? i0 + K : n;
+
+    unsigned long long sum = 0;
+    for (uint32_t i = i0; i < i1; i++)
+        sum += place_need(job, i);
+    // exclusive scan over the workgroup
+    unsigned long long incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long up = __shfl_up(incl, off, 64);
+        if ((int)(t & 63u) >= off)
+            incl += up;
+    }
+    if ((t & 63u) == 63u)
+        wave_tot[t >> 6] = incl;
+    __syncthreads();
+    unsigned long long base = incl - sum, total = 0;
+    for (uint32_t w = 0; w < kPlaceThreads / 64; w++) {
+        if (w < (t >> 6))
+            base += wave_tot[w];
+        total += wave_tot[w];
+    }
+    {
+        unsigned long long running = base;
+        for (uint32_t i = i0; i < i1; i++) {
+            if (i % tiles_per_raster == 0)
+                P[i / tiles_per_raster] = running;
+            running += place_need(job, i);
+        }
+    }
+    if (t == 0)
+        P[n_rasters] = total;
+    __syncthreads();
+    if (t == 0) {
+        const unsigned long long a = seg_align;
+        seg[0] = 0;
+        for (uint32_t r = 1; r <= n_rasters; r++) {
+            const unsigned long long end = seg[r - 1] + (P[r] - P[r - 1]);
+            seg[r] = r < n_rasters ? (end + a - 1) / a * a : end;
+        }
+        *job.cursor = seg[n_rasters];
+    }
+    __syncthreads();
+    {
+        unsigned long long running = base;
+        for (uint32_t i = i0; i < i1; i++) {
+            Book *b = reinterpret_cast<Book *>(job.books + (size_t)i * kBookBytes);
+            const uint32_t r = i / tiles_per_raster;
+            const uint32_t need = place_need(job, i);
+            if (b->slot != kAliasSlot) {
+                const unsigned long long off = seg[r] + (running - P[r]);
+                const bool fits = off + need <= job.arena_cap;
+                b->slot = fits ? (uint32_t)off : 0xffffffffu;
+                job.table[(size_t)i * 2] = fits ? (uint32_t)off : 0xffffffffu;
+                job.table[(size_t)i * 2 + 1] = fits ? b->stream_bytes : 0u;
+            }
+            running += need;
+        }
+    }
+    // the pad between a raster's last stream and the next raster's extent reads as zeros
+    for (uint32_t r = 0; r + 1 < n_rasters; r++) {
+        const unsigned long long from = seg[r] + (P[r + 1] - P[r]);
+        const unsigned long long to = seg[r + 1] < job.arena_cap ? seg[r + 1] : job.arena_cap;
+        for (unsigned long long o = from + (unsigned long long)t * 16u; o + 16u <= to; o += (unsigned long long)kPlaceThreads * 16u)
+            *reinterpret_cast<gcn10::u32x4 *>(job.arena + o) = gcn10::u32x4{ 0u, 0u, 0u, 0u };
     }
 }
 
@@ -1172,6 +1262,8 @@ int deflate_launch_codes(gcn10_gpu_ctx *ctx, const TileJob &job, uint32_t nblock
         hipLaunchKernelGGL(deflate_codes_kernel, dim3((nblocks + kBuildThreads - 1) / kBuildThreads),
                            dim3(kBuildThreads), sizeof(Work) * kBuildThreads, s, job);
     }
+    hipLaunchKernelGGL(deflate_place_kernel, dim3(1), dim3(kPlaceThreads), 0, s, job, job.across * job.down,
+                       (uint32_t)ctx->arena_segment_align);
     HIP_TRY(hipGetLastError());
     return GCN10_OK;
 }
@@ -1186,7 +1278,8 @@ size_t gcn10_gpu_deflate_arena_bound(int W, int rows, int n_rasters)
         return 0;
     const size_t across = ((size_t)W + kTile - 1) / kTile, down = ((size_t)rows + kTile - 1) / kTile;
     const size_t slot = ((size_t)kMaxStream + kSlotAlign - 1) / kSlotAlign * kSlotAlign;
-    return across * down * (size_t)n_rasters * slot;
+    // + the pads that bring every raster's extent to a multiple of the largest segment alignment
+    return across * down * (size_t)n_rasters * slot + (size_t)n_rasters * 4096u;
 }
 
 int gcn10_gpu_deflate_strip(gcn10_gpu_ctx *ctx, const uint8_t *const *rasters_dev, int n_rasters, int W,

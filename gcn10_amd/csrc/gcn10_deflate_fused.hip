@@ -250,8 +250,6 @@ __global__ __launch_bounds__(kTile) void fused_stats_kernel(const FusedJob job)
     const uint32_t ty = tix / job.t.across, tx = tix - ty * job.t.across;
     const uint8_t *class_val = job.class_of + gcn10::kClassCodes * 256;
 
-    if (tix == 0 && t == 0)
-        *job.t.cursor = 0ull;                       // pass B reserves arena slots from here
     for (int i = t; i < gcn10::kClassCodes * 256 / 4; i += kTile)
         reinterpret_cast<uint32_t *>(sh.class_of)[i] = reinterpret_cast<const uint32_t *>(job.class_of)[i];
     {
@@ -525,7 +523,9 @@ __global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
         dlen0[k] = b->dist_len[0];
         dcode1[k] = (uint32_t)b->dist_code[1] | 63u << b->dist_len[1];      // + 6 extra bits: 256 - 193
         dlen1[k] = (uint32_t)b->dist_len[1] + 6u;
-        const uint32_t n_words = (b->stream_bytes + 3u) / 4u;
+        // (up to the slot's 16-byte end: the host writes a raster's streams of a strip as one extent,
+        // the few bytes between two streams included -- they are zeros, not whatever the arena held)
+        const uint32_t n_words = (b->stream_bytes + 15u) / 16u * 4u;
         for (uint32_t i = t; i < n_words; i += kTile)
             words[k][i] = i < 64u ? b->header[i] : 0u;
         for (int i = t; i < 288; i += kTile) {

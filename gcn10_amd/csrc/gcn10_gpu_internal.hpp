@@ -69,6 +69,7 @@ struct gcn10_gpu_ctx {
     hipEvent_t time_start = nullptr, time_stop = nullptr;  // one-shot: bracket the next strip kernel
     uint8_t *d_class_of = nullptr;  // [36][256] pixel class of (soil code, landcover), then [18][256] values
     int n_classes = 0;              // 0: not available (set_tables not called, or > 256 classes)
+    int arena_segment_align = 4096; // tile encoder: a raster's streams of a strip start at a multiple of this (16 .. 4096)
     int deflate_wave_codes = 1;     // pass B of the tile encoder: 1 = one wave per tile, 0 = one thread
     int fused_diag = 0;             // timing experiments only (streams become invalid): 2 = pass F-C
                                     // without its token trips (set-up cost alone)

@@ -499,7 +499,7 @@ __device__ __forceinline__ void copy_match(Shared &sh, Output &o, uint32_t len, 
 struct TileIn {             // = gcn10_inflate_tile
     unsigned long long in_off;
     uint32_t in_len, out_len;
-    uint32_t chunk_w, src_x, src_y, copy_w, copy_h, pad;
+    uint32_t chunk_w, src_x, src_y, copy_w, copy_h, flags;       // GCN10_TILE_*
     unsigned long long dst_off;
 };
 static_assert(sizeof(TileIn) == sizeof(gcn10_inflate_tile), "TileIn mirrors the ABI struct");
@@ -1064,6 +1064,16 @@ __global__ __launch_bounds__(128) void inflate_kernel(const uint8_t *comp, const
     if (tile >= n_tiles)
         return;
     const TileIn tin = tiles[tile];
+    if (tin.flags & GCN10_TILE_RAW) {
+        // not a zlib stream: the chunk's bytes lie in `comp` as they are; untile_kernel copies the window
+        if (threadIdx.x == 0)
+            status[tile] = tin.in_len >= tin.out_len &&
+                                   window_ok(tin.out_len, tin.chunk_w, tin.src_x, tin.src_y, tin.copy_w, tin.copy_h,
+                                             0xffffffffu)
+                               ? 0u
+                               : (uint32_t)kErrWindow;
+        return;
+    }
 
     Decoder d;
     d.r.in = reinterpret_cast<const uint32_t *>(comp + tin.in_off);
@@ -1144,16 +1154,60 @@ __global__ __launch_bounds__(128) void inflate_kernel(const uint8_t *comp, const
         status[tile] = err;
 }
 
-// The wanted window of every decoded tile -> the row-major landcover block.
+// The wanted window of every decoded tile -> the row-major landcover block.  A raw tile
+// (GCN10_TILE_RAW: TIFF Compression 1) is read where it lies among the staged bytes; a tile
+// written with TIFF Predictor 2 (horizontal differencing, per chunk row) is summed back on the
+// way: byte x of a row = sum of the stored bytes 0..x of that row, modulo 256 -- the inverse the
+// host reader applies in tiff.c, decode_chunk().
 __global__ __launch_bounds__(256) void untile_kernel(const TileIn *tiles, const uint8_t *scratch, uint32_t slot_bytes,
-                                                     uint8_t *dst, unsigned long long dst_stride)
+                                                     const uint8_t *comp, uint8_t *dst, unsigned long long dst_stride)
 {
     typedef uint32_t u32_u __attribute__((aligned(1)));
     const TileIn tin = tiles[blockIdx.x];
-    if (!window_ok(tin.out_len, tin.chunk_w, tin.src_x, tin.src_y, tin.copy_w, tin.copy_h, slot_bytes))
+    const bool raw = (tin.flags & GCN10_TILE_RAW) != 0;
+    if (!window_ok(tin.out_len, tin.chunk_w, tin.src_x, tin.src_y, tin.copy_w, tin.copy_h, raw ? 0xffffffffu : slot_bytes) ||
+        (raw && tin.in_len < tin.out_len))
         return;                                 // inflate_kernel has set the status
-    const uint8_t *src = scratch + (size_t)blockIdx.x * slot_bytes + (size_t)tin.src_y * tin.chunk_w + tin.src_x;
+    const uint8_t *chunk = raw ? comp + tin.in_off : scratch + (size_t)blockIdx.x * slot_bytes;
     uint8_t *out = dst + tin.dst_off;
+    const int lane = (int)(threadIdx.x & 63u);
+    if (tin.flags & GCN10_TILE_PREDICTOR2) {
+        // one wave per row, 1024 stored bytes per trip: 16 per lane summed in the lane, the lanes' totals
+        // by a wave scan, the carry of the row's earlier trips on top
+        const uint32_t end = tin.src_x + tin.copy_w;            // bytes of the row that matter
+        for (uint32_t y = blockIdx.y * 4u + (threadIdx.x >> 6); y < tin.copy_h; y += gridDim.y * 4u) {
+            const uint8_t *s = chunk + (size_t)(tin.src_y + y) * tin.chunk_w;
+            uint8_t *d = out + (size_t)y * dst_stride;
+            uint32_t carry = 0;
+            for (uint32_t x0 = 0; x0 < end; x0 += 1024u) {
+                const uint32_t x = x0 + (uint32_t)lane * 16u;
+                uint8_t v[16];
+                uint32_t acc = 0;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    acc += x + (uint32_t)k < end ? s[x + (uint32_t)k] : 0u;
+                    v[k] = (uint8_t)acc;
+                }
+                uint32_t incl = acc & 0xffu;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t up = __shfl_up(incl, off, 64);
+                    if (lane >= off)
+                        incl += up;
+                }
+                const uint32_t before = carry + incl - (acc & 0xffu);
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const uint32_t xx = x + (uint32_t)k;
+                    if (xx >= tin.src_x && xx < end)
+                        d[xx - tin.src_x] = (uint8_t)(v[k] + before);
+                }
+                carry = (carry + (uint32_t)__shfl(incl, 63, 64)) & 0xffu;
+            }
+        }
+        return;
+    }
+    const uint8_t *src = chunk + (size_t)tin.src_y * tin.chunk_w + tin.src_x;
     const uint32_t w4 = tin.copy_w / 4u;
     for (uint32_t y = blockIdx.y * 4u + (threadIdx.x >> 6); y < tin.copy_h; y += gridDim.y * 4u) {
         const uint8_t *s = src + (size_t)y * tin.chunk_w;
@@ -1202,7 +1256,7 @@ int gcn10_gpu_inflate_tiles(gcn10_gpu_ctx *ctx, const uint8_t *comp_dev, const g
                        reinterpret_cast<const TileIn *>(tiles_dev), (uint32_t)n_tiles, scratch, slot, status_dev,
                        (uint32_t)ctx->inflate_diag);
     hipLaunchKernelGGL(untile_kernel, dim3((uint32_t)n_tiles, 16), dim3(256), 0, s,
-                       reinterpret_cast<const TileIn *>(tiles_dev), scratch, slot, dst_dev,
+                       reinterpret_cast<const TileIn *>(tiles_dev), scratch, slot, comp_dev, dst_dev,
                        (unsigned long long)dst_stride);
     HIP_TRY(hipGetLastError());
     return GCN10_OK;

@@ -105,6 +105,7 @@ int gcn10_config_parse(const char *path, gcn10_config *cfg, char *err, size_t er
     memset(cfg, 0, sizeof *cfg);
     cfg->gpu_deflate = 2;
     cfg->gpu_inflate = 1;
+    cfg->prefetch_blocks = 1;
     cfg->table_mask = 0x1ffu;
     cfg->cond_mask = 3u;
     f = fopen(path, "r");
@@ -148,6 +149,10 @@ int gcn10_config_parse(const char *path, gcn10_config *cfg, char *err, size_t er
             cfg->gpu_inflate = atoi(val) != 0;
         else if (!strcmp(key, "io_threads"))
             cfg->io_threads = atoi(val);
+        else if (!strcmp(key, "direct_io"))
+            cfg->direct_io = atoi(val) != 0;
+        else if (!strcmp(key, "prefetch_blocks"))
+            cfg->prefetch_blocks = atoi(val) != 0;
         else if (!strcmp(key, "deflate_level"))
             cfg->deflate_level = atoi(val);
         else if (!strcmp(key, "gpu_deflate"))

@@ -39,6 +39,8 @@ struct gcn10_chunk_ref {
     uint32_t src_x, src_y;      /* first wanted pixel of the chunk */
     uint32_t copy_w, copy_h;
     uint32_t dst_x, dst_y;      /* where it goes in the window */
+    uint32_t flags;             /* GCN10_TILE_RAW | GCN10_TILE_PREDICTOR2 (gcn10_inflate_tile.flags) */
+    uint32_t out_len;           /* bytes the chunk stands for on the device: decoded size, or nbytes of a raw one */
 };
 struct gcn10_read_plan {
     struct gcn10_chunk_ref *chunks;
@@ -46,10 +48,11 @@ struct gcn10_read_plan {
     struct gcn10_tiff **opened; /* VRT sources opened for this plan */
     int n_opened;
     uint64_t covered;           /* pixels of the window the chunks fill; the rest reads as 0 */
-    uint32_t max_chunk_bytes;   /* largest decoded chunk */
+    uint32_t max_chunk_bytes;   /* largest decoded DEFLATE chunk (raw chunks need no decode slot) */
+    uint64_t staged_bytes;      /* bytes of all chunks as they cross PCIe */
 };
-/* 0 = planned; 1 = this window cannot be decoded on the GPU (other compression, predictor,
- * overlapping mosaic sources ...): use gcn10_raster_read_mt; -1 = error (err is set). */
+/* 0 = planned; 1 = this window is left to the host reader (LZW / PackBits, overlapping mosaic
+ * sources, full-width raw strips of a much wider raster ...): use gcn10_raster_read_mt; -1 = error (err is set). */
 int gcn10_raster_plan_window(gcn10_raster *r, int xoff, int yoff, int xcount, int ycount,
                              struct gcn10_read_plan *plan, char *err, size_t errcap);
 int gcn10_tiff_plan_window(struct gcn10_tiff *t, int xoff, int yoff, int xcount, int ycount, int dst_x,

@@ -5,15 +5,15 @@
  * landcover window and the soil window with GDAL, upsample, then 18 times
  * {read CSV, memcpy, remap, memset, lookup, GDAL DEFLATE write}.
  *
- * Here, per block on one GPU worker thread:
- *   host   bbox -> windows (geo.c, bit-exact) -> soil window + index maps -> HBM
- *   strips landcover rows are decoded straight into a pinned strip buffer,
- *          copied to HBM on the h2d stream, turned into 18 CN strips by ONE
- *          fused kernel on the compute stream, copied back on the d2h stream
- *          into pinned strip buffers; two buffer sets rotate, so file decode,
- *          H2D, kernel, D2H and tile compression of neighbouring strips overlap
- *   sink   every 256x256 tile of every raster of a finished strip is a job for
- *          the compression pool, which appends it to the raster's GeoTIFF
+ * Here, per block, two threads per GPU worker:
+ *   input  (pipeline_input.c, one block AHEAD): bbox -> windows (geo.c, bit-exact) -> soil window +
+ *          index maps -> HBM; the landcover window's chunks as they lie in the files -> pinned ring ->
+ *          HBM -> decoded / untiled there into the row-major block
+ *   encode (here): per strip of rows ONE fused device pass turns landcover + soil into the compressed
+ *          256x256 tiles of all 18 rasters (no CN raster in HBM); the tiles of a raster and a strip are
+ *          one extent of the arena, copied back on the d2h stream into pinned memory; buffer sets rotate,
+ *          so kernels, copy-back and file writes of neighbouring strips overlap
+ *   sink   one write per raster and strip appends the extent to the raster's GeoTIFF (I/O pool)
  * Blocks are pulled from one atomic counter by all workers (the reference's
  * static `i += size` round-robin, src/main.c:171, made dynamic); no data moves
  * between GPUs, so there is no collective and no RCCL.
@@ -56,7 +56,6 @@ void gcn10_wlog(struct worker *w, const char *level, bool console, const char *f
 
 #define now_seconds gcn10_now_seconds
 #define wlog gcn10_wlog
-#define ensure_dev gcn10_ensure_dev
 
 /* ------------------------------------------------------------------------ */
 /* sink: tile compression jobs                                               */
@@ -114,8 +113,10 @@ static void put_tiles_job(void *arg)
     const bool arrived = j->w->run->gpu->event_sync(j->w->ctx, j->b->ev_d2h) == 0;  /* the strip's compressed bytes */
     int *txs = malloc(n * sizeof *txs), *tys = malloc(n * sizeof *tys);
     const void **data = malloc(n * sizeof *data);
-    uint32_t *sizes = malloc(n * sizeof *sizes);
-    bool ok = arrived && txs && tys && data && sizes;
+    uint32_t *sizes = malloc(n * sizeof *sizes), *rel = malloc(n * sizeof *rel);
+    bool ok = arrived && txs && tys && data && sizes && rel;
+    bool extent = true;             /* the streams lie back to back in tile order (16-byte slots) */
+    uint32_t first = 0, end = 0;
 
     for (int ty = 0; ok && ty < j->down; ty++) {
         for (int tx = 0; tx < j->across; tx++) {
@@ -131,15 +132,29 @@ static void put_tiles_job(void *arg)
             tys[i] = j->ty0 + ty;
             data[i] = j->b->h_tiles + off;
             sizes[i] = size;
+            if (i == 0)
+                first = off;
+            else if (off != ((end + 15u) & ~15u))
+                extent = false;
+            rel[i] = off - first;
+            end = off + size;
         }
     }
-    /* the strip's tiles of this raster: gathered writes, 512 tiles per system call */
-    if (!ok || gcn10_tiff_put_tiles(j->tif, (int)n, txs, tys, data, sizes) != 0)
+    /* The GPU encoders lay a raster's streams of a strip out as ONE extent in tile order (pass B'): one
+     * write appends them all.  (An alias raster of the fused encoder -- its tiles ARE another raster's
+     * streams -- points into that raster's extent: the same test holds when every tile is aliased alike;
+     * a mixture falls back to gathered writes, 512 tiles per system call.) */
+    if (ok && extent)
+        ok = gcn10_tiff_put_extent(j->tif, j->b->h_tiles + first, (size_t)(end - first), (int)n, txs, tys, rel, sizes) == 0;
+    else if (ok)
+        ok = gcn10_tiff_put_tiles(j->tif, (int)n, txs, tys, data, sizes) == 0;
+    if (!ok)
         atomic_store(&j->w->failed, true);
     free(txs);
     free(tys);
     free(data);
     free(sizes);
+    free(rel);
     pthread_mutex_lock(&j->b->mu);
     if (--j->b->pending == 0)
         pthread_cond_broadcast(&j->b->cv);
@@ -204,7 +219,7 @@ static int drain_strip_inner(struct worker *w, struct strip_buf *b, gcn10_tiff_w
             free(b->h_spill);
             b->h_spill = NULL;
             if (used > b->h_arena_cap) {
-                b->h_spill = malloc(used);
+                b->h_spill = aligned_alloc(4096, (used + 4095) & ~(size_t)4095);
                 if (!b->h_spill) {
                     wlog(w, "ERROR", true, "malloc failed for %zu bytes of compressed tiles", used);
                     return -1;
@@ -214,7 +229,9 @@ static int drain_strip_inner(struct worker *w, struct strip_buf *b, gcn10_tiff_w
             b->h_tiles = dst;
             b->h_tiles_used = used;
             /* the sink jobs wait for this copy themselves: the worker goes on to the next strip */
-            if (g->memcpy_d2h(w->ctx, dst, b->d_arena, used, w->s_d2h) != 0 ||
+            /* (whole 4096-byte units: an O_DIRECT write of the last extent reads up to the next multiple;
+             * both arenas are that much larger than `used` can get) */
+            if (g->memcpy_d2h(w->ctx, dst, b->d_arena, (used + 4095) & ~(size_t)4095, w->s_d2h) != 0 ||
                 g->event_record(w->ctx, b->ev_d2h, w->s_d2h) != 0)
                 goto gpu_error;
         }
@@ -281,8 +298,6 @@ static void free_strip_buffers(struct worker *w)
     for (int i = 0; i < w->run->nbuf; i++) {
         struct strip_buf *b = &w->buf[i];
 
-        if (b->h_esa) g->host_free(w->ctx, b->h_esa);
-        if (b->d_esa) g->free(w->ctx, b->d_esa);
         for (int k = 0; k < GCN10_N_RASTERS; k++) {
             if (b->h_out[k]) g->host_free(w->ctx, b->h_out[k]);
             if (b->d_out[k]) g->free(w->ctx, b->d_out[k]);
@@ -301,8 +316,6 @@ static void free_strip_buffers(struct worker *w)
         b->h_table = b->d_table = NULL;
         b->h_cursor = b->d_cursor = NULL;
         b->d_ptrs = NULL;
-        b->h_esa = b->d_esa = NULL;
-        b->esa_px = 0;
     }
     w->buf_px = 0;
     w->buf_tiles = 0;
@@ -321,7 +334,6 @@ static int ensure_strip_buffers(struct worker *w, int W)
     for (int i = 0; i < w->run->nbuf; i++) {
         struct strip_buf *b = &w->buf[i];
 
-        /* (landcover staging h_esa / d_esa: only when a block goes through the host reader) */
         for (int q = 0; q < w->run->n_sel; q++) {
             const int k = w->run->sel[q];
 
@@ -334,7 +346,7 @@ static int ensure_strip_buffers(struct worker *w, int W)
             size_t tiles = n_tiles;
 
             b->arena_cap = g->deflate_arena_bound(W, w->strip_rows, GCN10_N_RASTERS);
-            GPU_TRY(w, g->malloc(w->ctx, b->arena_cap, (void **)&b->d_arena));
+            GPU_TRY(w, g->malloc(w->ctx, b->arena_cap + 4096, (void **)&b->d_arena));
             b->h_arena_cap = b->arena_cap / 8 > ((size_t)32 << 20) ? b->arena_cap / 8 : ((size_t)32 << 20);
             if (getenv("GCN10_PINNED_ARENA_BYTES"))        /* tests: force the spill path */
                 b->h_arena_cap = (size_t)strtoull(getenv("GCN10_PINNED_ARENA_BYTES"), NULL, 10);
@@ -342,7 +354,8 @@ static int ensure_strip_buffers(struct worker *w, int W)
                 b->h_arena_cap = 4096;
             if (b->h_arena_cap > b->arena_cap)
                 b->h_arena_cap = b->arena_cap;
-            GPU_TRY(w, g->host_alloc(w->ctx, b->h_arena_cap, (void **)&b->h_arena));
+            b->h_arena_cap &= ~(size_t)4095;
+            GPU_TRY(w, g->host_alloc(w->ctx, b->h_arena_cap + 4096, (void **)&b->h_arena));
             GPU_TRY(w, g->malloc(w->ctx, tiles * GCN10_N_RASTERS * 8, (void **)&b->d_table));
             GPU_TRY(w, g->host_alloc(w->ctx, tiles * GCN10_N_RASTERS * 8, (void **)&b->h_table));
             GPU_TRY(w, g->malloc(w->ctx, 8, (void **)&b->d_cursor));
@@ -365,33 +378,33 @@ static int ensure_strip_buffers(struct worker *w, int W)
     return 0;
 }
 
-static int ensure_pinned(struct worker *w, void **p, size_t *cap, size_t need)
+int gcn10_ensure_pinned_on(struct worker *w, gcn10_gpu_ctx *ctx, void **p, size_t *cap, size_t need)
 {
     const struct gcn10_gpu_api *g = w->run->gpu;
 
     if (need <= *cap)
         return 0;
     if (*p)
-        g->host_free(w->ctx, *p);
+        g->host_free(ctx, *p);
     *p = NULL;
     *cap = 0;
     need += need / 8 + 4096;
-    GPU_TRY(w, g->host_alloc(w->ctx, need, p));
+    GPU_TRY(w, g->host_alloc(ctx, need, p));
     *cap = need;
     return 0;
 }
 
-int gcn10_ensure_dev(struct worker *w, void **p, size_t *cap, size_t need)
+int gcn10_ensure_dev_on(struct worker *w, gcn10_gpu_ctx *ctx, void **p, size_t *cap, size_t need)
 {
     const struct gcn10_gpu_api *g = w->run->gpu;
 
     if (need <= *cap)
         return 0;
     if (*p)
-        GPU_TRY(w, g->free(w->ctx, *p));
+        GPU_TRY(w, g->free(ctx, *p));
     *p = NULL;
     *cap = 0;
-    GPU_TRY(w, g->malloc(w->ctx, need, p));
+    GPU_TRY(w, g->malloc(ctx, need, p));
     *cap = need;
     return 0;
 }
@@ -416,73 +429,19 @@ static void output_path(char *out, size_t cap, const char *cond, const char *hc,
     }
 }
 
-/* returns 0 (done or skipped like the reference skips) or -1 for errors the
+/* The back half of process_block (src/cn.c:236-384) for a block whose input the input side has put on its
+ * way to HBM.  Returns 0 (done, or skipped like the reference skips) or -1 for errors the
  * reference answers with MPI_Abort */
-static int process_block(struct worker *w, int block_id)
+static int encode_block(struct worker *w, struct block_in *in)
 {
     struct run *r = w->run;
     const struct gcn10_gpu_api *g = r->gpu;
     char err[1024] = "";
-    double esa_t[6], soil_t[6], gt[6], soil_gt[6];
-    int esa_rx, esa_ry, soil_rx, soil_ry;
-    int xoff, yoff, W, H, sxoff, syoff, hsx, hsy;
-    uint8_t *coarse = NULL;
-    int32_t *ci = NULL, *cj = NULL;
+    const int W = in->W, H = in->H, block_id = in->block_id;
     gcn10_tiff_writer *tifs[GCN10_N_RASTERS] = { 0 };
-    int rc = 0, bi, n_strips;
-    bool ok = false, inflated = false;
+    int rc = 0, n_strips;
+    bool ok = false;
     double t_mark = now_seconds();
-
-    /* block geometry: attribute filter "ID"=<id>, first feature (src/cn.c:162-184) */
-    bi = gcn10_blocks_find(&r->blocks, block_id);
-    if (bi < 0) {
-        wlog(w, "ERROR", true, "block %d not found", block_id);                 /* src/cn.c:173 */
-        return 0;
-    }
-
-    /* landcover window (src/cn.c:187-192, src/raster.c:126-162) */
-    gcn10_raster_info(w->esa, &esa_rx, &esa_ry, esa_t);
-    if (gcn10_raster_window(esa_t, esa_rx, esa_ry, r->blocks.bbox[bi], &xoff, &yoff, &W, &H, gt) != 0) {
-        wlog(w, "ERROR", true, "invalid raster bounds for %s", r->cfg.esa_data_path);   /* src/raster.c:143 */
-        wlog(w, "ERROR", true, "esa load failed for block %d", block_id);               /* src/cn.c:189 */
-        return 0;
-    }
-    /* soil window (src/cn.c:195-203) */
-    gcn10_raster_info(w->soil, &soil_rx, &soil_ry, soil_t);
-    if (gcn10_raster_window(soil_t, soil_rx, soil_ry, r->blocks.bbox[bi], &sxoff, &syoff, &hsx, &hsy,
-                            soil_gt) != 0) {
-        wlog(w, "ERROR", true, "invalid raster bounds for %s", r->cfg.hysogs_data_path);
-        wlog(w, "ERROR", true, "hysogs load failed for block %d", block_id);            /* src/cn.c:198 */
-        return 0;
-    }
-    if ((long long)W * (long long)H > INT_MAX) {
-        /* the reference's int npix (src/cn.c:208) overflows here; refuse instead */
-        wlog(w, "ERROR", true, "block %d: %d x %d pixels exceed 2^31-1", block_id, W, H);
-        return 0;
-    }
-    /* soil window and index maps live in pinned memory owned by the worker: their copies to the
-     * GPU need no wait (the previous block, which used the same buffers, has drained) */
-    if (ensure_pinned(w, (void **)&w->h_coarse, &w->h_coarse_cap, (size_t)hsx * (size_t)hsy) != 0 ||
-        ensure_pinned(w, (void **)&w->h_ci, &w->h_ci_cap, (size_t)W * sizeof *ci) != 0 ||
-        ensure_pinned(w, (void **)&w->h_cj, &w->h_cj_cap, (size_t)H * sizeof *cj) != 0) {
-        wlog(w, "ERROR", true, "malloc failed for hysogs resampling, block %d", block_id); /* src/cn.c:211 */
-        rc = -1;
-        goto out;
-    }
-    coarse = w->h_coarse;
-    ci = w->h_ci;
-    cj = w->h_cj;
-    t_mark = now_seconds();
-    /* the soil raster is a global file of full-width strips: a block's window touches ~1440 of
-     * them, decoded concurrently on the I/O pool and only as far as the window reaches */
-    if (gcn10_raster_read_mt(w->soil, sxoff, syoff, hsx, hsy, coarse, r->pool, err, sizeof err) != 0) {
-        wlog(w, "ERROR", true, "%s", err);
-        wlog(w, "ERROR", true, "hysogs load failed for block %d", block_id);
-        goto out;
-    }
-    gcn10_build_index_maps(gt, soil_gt, W, H, hsx, hsy, ci, cj);       /* src/cn.c:218-229 */
-    w->t_soil += now_seconds() - t_mark;
-    t_mark = now_seconds();
 
     /* output directories (src/cn.c:237-256) and the 18 files */
     for (int c = 0; c < 2 && !r->null_sink; c++) {
@@ -503,52 +462,31 @@ static int process_block(struct worker *w, int block_id)
 
         output_path(path, sizeof path, gcn10_conds[k / 9], gcn10_hcs[(k % 9) / 3], gcn10_arcs[k % 3],
                     block_id, r->opt.overwrite);
-        tifs[k] = gcn10_tiff_create(path, W, H, gt, gcn10_raster_georef(w->esa), err, sizeof err);
+        tifs[k] = gcn10_tiff_create(path, W, H, in->gt, gcn10_raster_georef(w->esa), err, sizeof err);
         if (!tifs[k]) {
             wlog(w, "ERROR", true, "%s", err);          /* save_raster logs and goes on, src/raster.c:220-223 */
             goto out;
         }
+        if (r->direct_io && r->gpu_deflate)
+            gcn10_tiff_set_direct(tifs[k], true);       /* best effort: a file system that refuses writes buffered */
     }
-
     w->t_create += now_seconds() - t_mark;
     t_mark = now_seconds();
 
-    /* device side of the block */
+    /* device side of the block: the encoder waits (on the device) for the input side's copies and kernels */
     w->strip_rows = r->strip_rows;
-    if (ensure_strip_buffers(w, W) != 0 ||
-        ensure_dev(w, (void **)&w->d_coarse, &w->coarse_cap, (size_t)hsx * hsy) != 0 ||
-        ensure_dev(w, (void **)&w->d_ci, &w->ci_cap, (size_t)W * 4) != 0 ||
-        ensure_dev(w, (void **)&w->d_cj, &w->cj_cap, (size_t)H * 4) != 0) {
+    if (ensure_strip_buffers(w, W) != 0) {
         rc = -1;
         goto out;
     }
     atomic_store(&w->failed, false);
-    if (g->memcpy_h2d(w->ctx, w->d_coarse, coarse, (size_t)hsx * hsy, w->s_kernel) != 0 ||
-        g->memcpy_h2d(w->ctx, w->d_ci, ci, (size_t)W * 4, w->s_kernel) != 0 ||
-        g->memcpy_h2d(w->ctx, w->d_cj, cj, (size_t)H * 4, w->s_kernel) != 0 ||
-        g->prepare_tile(w->ctx, w->d_coarse, hsx, hsy, w->d_ci, W, w->s_kernel) != 0) {
+    if (g->stream_wait_event(w->ctx, w->s_kernel, in->ev_ready) != 0 ||
+        g->prepare_tile(w->ctx, in->d_coarse, in->hsx, in->hsy, in->d_ci, W, w->s_kernel) != 0) {
         wlog(w, "ERROR", true, "gpu: %s", g->last_error());
         rc = -1;
         goto out;
     }
-
     w->t_device += now_seconds() - t_mark;
-
-    /* DEFLATE landcover (the ESA tiles): compressed chunks -> HBM -> decoded there */
-    w->n_inflate = 0;
-    if (r->gpu_inflate) {
-        int irc = gcn10_inflate_block(w, xoff, yoff, W, H, block_id);
-
-        if (irc == -2) {
-            rc = -1;                /* device error: fatal like every other GPU error here (the worker's
-                                     * streams are synchronised at `out` before any buffer is reused) */
-            goto out;
-        }
-        if (irc < 0) {
-            goto out;               /* logged; the block is skipped as after a failed load_raster */
-        }
-        inflated = irc == 0;
-    }
 
     /* strips: rows are multiples of 256 (whole GeoTIFF tile rows) and of 16
      * (16-byte aligned strip starts for any W) */
@@ -559,6 +497,7 @@ static int process_block(struct worker *w, int block_id)
         int rows = H - y0 < w->strip_rows ? H - y0 : w->strip_rows;
         size_t px = (size_t)W * (size_t)rows;
         uint8_t *outs[GCN10_N_RASTERS];
+        const uint8_t *d_esa = in->d_block + (size_t)y0 * (size_t)W;
 
         /* this buffer's previous strip: its D2H must be done and handed to the sink,
          * and the sink must be done with the pinned buffers */
@@ -568,50 +507,17 @@ static int process_block(struct worker *w, int block_id)
         }
         wait_sink(b);
 
-        const uint8_t *d_esa = inflated ? w->d_block + (size_t)y0 * (size_t)W : b->d_esa;   /* (set below if not yet) */
-
-        if (!inflated) {
-            /* landcover rows straight into the pinned strip (replaces the malloc +
-             * GDALRasterIO of src/raster.c:169-178) */
-            double t_r0 = now_seconds();
-
-            if (!b->h_esa || b->esa_px < w->buf_px) {
-                if (b->h_esa) g->host_free(w->ctx, b->h_esa);
-                if (b->d_esa) g->free(w->ctx, b->d_esa);
-                b->h_esa = b->d_esa = NULL;
-                b->esa_px = 0;
-                if (g->host_alloc(w->ctx, w->buf_px, (void **)&b->h_esa) != 0 ||
-                    g->malloc(w->ctx, w->buf_px, (void **)&b->d_esa) != 0)
-                    goto gpu_fail;
-                b->esa_px = w->buf_px;
-                d_esa = b->d_esa;
-            }
-            /* the strip's landcover tiles are decoded concurrently on the I/O pool */
-            int read_rc = gcn10_raster_read_mt(w->esa, xoff, yoff + y0, W, rows, b->h_esa, r->pool, err,
-                                               sizeof err);
-
-            w->t_read += now_seconds() - t_r0;
-            if (read_rc != 0) {
-                wlog(w, "ERROR", true, "%s", err);
-                wlog(w, "ERROR", true, "esa load failed for block %d", block_id);
-                goto out;
-            }
-            if (g->memcpy_h2d(w->ctx, b->d_esa, b->h_esa, px, w->s_h2d) != 0 ||
-                g->event_record(w->ctx, b->ev_h2d, w->s_h2d) != 0 ||
-                g->stream_wait_event(w->ctx, w->s_kernel, b->ev_h2d) != 0)
-                goto gpu_fail;
-        }
         /* the strip's kernels on the compute stream */
         if (w->fused) {
             /* landcover + soil -> 18 x compressed tiles in one device pass, no CN strip in HBM */
-            if (g->deflate_fused_strip(w->ctx, d_esa, W, rows, w->d_cj + y0, r->cond_mask, r->table_mask, b->d_arena,
+            if (g->deflate_fused_strip(w->ctx, d_esa, W, rows, in->d_cj + y0, r->cond_mask, r->table_mask, b->d_arena,
                                        b->arena_cap, b->d_table, b->d_cursor, w->s_kernel) != 0)
                 goto gpu_fail;
         }
         else {
             for (int k = 0; k < GCN10_N_RASTERS; k++)
                 outs[k] = b->d_out[k];             /* NULL for a raster this run does not produce */
-            if (g->cn_strip(w->ctx, d_esa, W, rows, w->d_cj + y0, r->cond_mask, r->table_mask, outs,
+            if (g->cn_strip(w->ctx, d_esa, W, rows, in->d_cj + y0, r->cond_mask, r->table_mask, outs,
                             w->s_kernel) != 0)
                 goto gpu_fail;
             /* encode the selected strips where they are */
@@ -659,14 +565,14 @@ static int process_block(struct worker *w, int block_id)
     for (int i = 0; i < w->run->nbuf; i++)
         wait_sink(&w->buf[i]);
     ok = !atomic_load(&w->failed);
-    if (inflated && w->n_inflate > 0) {
-        /* every landcover stream must have been a valid one */
-        if (g->event_sync(w->ctx, w->ev_inflate) != 0)
+    if (in->n_inflate > 0) {
+        /* every landcover chunk must have been a valid one (the statuses came back behind ev_ready) */
+        if (g->event_sync(w->ctx, in->ev_ready) != 0)
             goto gpu_fail;
-        for (size_t i = 0; i < w->n_inflate; i++)
-            if (w->h_status[i] != 0) {
+        for (size_t i = 0; i < in->n_inflate; i++)
+            if (in->h_status[i] != 0) {
                 wlog(w, "ERROR", true, "gdalrasterio error: cannot decode a tile of the window %d,%d %dx%d "
-                                       "(stream %zu, reason %u)", xoff, yoff, W, H, i, w->h_status[i]);
+                                       "(stream %zu, reason %u)", in->xoff, in->yoff, W, H, i, in->h_status[i]);
                 wlog(w, "ERROR", true, "esa load failed for block %d", block_id);
                 ok = false;
                 break;
@@ -690,7 +596,7 @@ out:
     if (rc != 0 && w->ctx)
         g->device_sync(w->ctx);
     else if (!ok && w->ctx)
-        g->stream_sync(w->ctx, w->s_kernel);    /* a skipped block: its soil copies may still be queued */
+        g->stream_sync(w->ctx, w->s_kernel);    /* a block given up half-way: its kernels may still be queued */
     t_mark = now_seconds();
     for (int k = 0; k < GCN10_N_RASTERS; k++) {
         if (!tifs[k])
@@ -706,7 +612,7 @@ out:
         tifs[k] = NULL;
     }
     w->t_finish += now_seconds() - t_mark;
-    if (ok || (r->null_sink && rc == 0 && !atomic_load(&w->failed))) {
+    if (ok) {
         for (int q = 0; q < r->n_sel; q++) {
             const int k = r->sel[q];
             /* src/cn.c:366-373: one completion line and one progress line per raster */
@@ -732,6 +638,7 @@ static void worker_teardown(struct worker *w)
 {
     const struct gcn10_gpu_api *g = w->run->gpu;
 
+    gcn10_input_teardown(w);
     if (w->ctx) {
         g->device_sync(w->ctx);
         free_strip_buffers(w);
@@ -743,22 +650,6 @@ static void worker_teardown(struct worker *w)
             if (b->ev_d2h) g->event_destroy(w->ctx, b->ev_d2h);
             if (b->ev_meta) g->event_destroy(w->ctx, b->ev_meta);
         }
-        if (w->ev_comp) g->event_destroy(w->ctx, w->ev_comp);
-        if (w->ev_inflate) g->event_destroy(w->ctx, w->ev_inflate);
-        if (w->h_comp) g->host_free(w->ctx, w->h_comp);
-        if (w->d_comp) g->free(w->ctx, w->d_comp);
-        if (w->h_jobs) g->host_free(w->ctx, w->h_jobs);
-        if (w->d_jobs) g->free(w->ctx, w->d_jobs);
-        if (w->h_status) g->host_free(w->ctx, w->h_status);
-        if (w->d_status) g->free(w->ctx, w->d_status);
-        if (w->d_block) g->free(w->ctx, w->d_block);
-        if (w->h_coarse) g->host_free(w->ctx, w->h_coarse);
-        if (w->h_ci) g->host_free(w->ctx, w->h_ci);
-        if (w->h_cj) g->host_free(w->ctx, w->h_cj);
-        if (w->d_coarse) g->free(w->ctx, w->d_coarse);
-        if (w->d_ci) g->free(w->ctx, w->d_ci);
-        if (w->d_cj) g->free(w->ctx, w->d_cj);
-        if (w->s_h2d) g->stream_destroy(w->ctx, w->s_h2d);
         if (w->s_kernel) g->stream_destroy(w->ctx, w->s_kernel);
         if (w->s_d2h) g->stream_destroy(w->ctx, w->s_d2h);
         g->destroy(w->ctx);
@@ -861,11 +752,8 @@ static int worker_setup(struct worker *w)
     if (r->fused && !w->fused)
         wlog(w, "INFO", false, "the lookup tables define more than 256 pixel classes: "
                                "per-raster GPU encoding instead of the fused encoder");
-    GPU_TRY(w, g->stream_create(w->ctx, &w->s_h2d));
     GPU_TRY(w, g->stream_create(w->ctx, &w->s_kernel));
     GPU_TRY(w, g->stream_create(w->ctx, &w->s_d2h));
-    GPU_TRY(w, g->event_create(w->ctx, &w->ev_comp));
-    GPU_TRY(w, g->event_create(w->ctx, &w->ev_inflate));
     for (int i = 0; i < w->run->nbuf; i++) {
         GPU_TRY(w, g->event_create(w->ctx, &w->buf[i].ev_h2d));
         GPU_TRY(w, g->event_create(w->ctx, &w->buf[i].ev_kernel));
@@ -880,6 +768,9 @@ static int worker_setup(struct worker *w)
     w->soil = gcn10_raster_open(r->cfg.hysogs_data_path, NULL, err, sizeof err);
     if (!w->soil)
         wlog(w, "ERROR", true, "%s", err);
+    /* the input side: its own context and stream on the same device, and (prefetch_blocks=1) its thread */
+    if (gcn10_input_setup(w) != 0 || gcn10_input_start(w) != 0)
+        return -1;
     return 0;
 }
 
@@ -894,31 +785,22 @@ static void *worker_main(void *arg)
         return NULL;
     }
     for (;;) {
-        int i = atomic_fetch_add(&r->next_block, 1);
-        int id;
+        /* the next block of THIS worker: staged one block ahead by its input thread, which takes the ids
+         * from the run's counter (the reference's `i += size`, src/main.c:171, made dynamic) */
+        struct block_in *in = gcn10_input_next(w);
         double t0;
 
-        if (i >= r->n_blocks || atomic_load(&r->fatal))
+        if (!in)
             break;
-        id = r->block_ids[i];
-        wlog(w, "INFO", true, "processing block %d", id);               /* src/main.c:172-173 */
-        if (!w->esa) {
-            wlog(w, "ERROR", true, "esa load failed for block %d", id); /* src/cn.c:189 */
-            continue;
-        }
-        if (!w->soil) {
-            wlog(w, "ERROR", true, "hysogs load failed for block %d", id);
-            continue;
-        }
         t0 = now_seconds();
-        if (w->t_first_block == 0.0)
-            w->t_first_block = t0;
-        if (process_block(w, id) != 0) {
+        if (in->outcome == 0 && !atomic_load(&r->fatal) && encode_block(w, in) != 0)
             atomic_store(&r->fatal, 1);     /* where the reference calls MPI_Abort */
-            break;
-        }
         w->busy_seconds += now_seconds() - t0;
-        w->blocks_done++;
+        w->blocks_done += in->outcome >= 0 ? 1 : 0;
+        w->in_seq++;
+        gcn10_input_release(w, in);
+        if (atomic_load(&r->fatal))
+            break;
     }
     worker_teardown(w);
     return NULL;
@@ -1012,6 +894,8 @@ int gcn10_run(const gcn10_run_options *opt)
     r->gpu_deflate = r->cfg.gpu_deflate != 0;
     r->fused = r->cfg.gpu_deflate == 2;
     r->gpu_inflate = r->cfg.gpu_inflate != 0;
+    r->direct_io = r->cfg.direct_io != 0 || (getenv("GCN10_DIRECT_IO") && atoi(getenv("GCN10_DIRECT_IO")) != 0);
+    r->prefetch = r->cfg.prefetch_blocks != 0 && !(getenv("GCN10_PREFETCH_BLOCKS") && atoi(getenv("GCN10_PREFETCH_BLOCKS")) == 0);
     r->nbuf = DEFAULT_NBUF;
     if (getenv("GCN10_STRIP_BUFFERS")) {
         int n = atoi(getenv("GCN10_STRIP_BUFFERS"));
@@ -1202,7 +1086,7 @@ int gcn10_run(const gcn10_run_options *opt)
     gcn10_log_message(log0, "INFO", msg, true);
     {
         int done_blocks = 0;
-        double busy = 0, rd = 0, gw = 0, sw = 0, so = 0, cr = 0, fi = 0, dv = 0, steady = 0;
+        double busy = 0, rd = 0, gw = 0, sw = 0, so = 0, cr = 0, fi = 0, dv = 0, steady = 0, iw = 0, ib = 0;
 
         for (int i = 0; i < r->n_workers; i++) {
             done_blocks += r->workers[i].blocks_done;
@@ -1214,6 +1098,8 @@ int gcn10_run(const gcn10_run_options *opt)
             cr += r->workers[i].t_create;
             fi += r->workers[i].t_finish;
             dv += r->workers[i].t_device;
+            iw += r->workers[i].t_in_wait;
+            ib += r->workers[i].t_in_busy;
         }
         {
             /* from the moment the first worker had its GPU, buffers and files ready: what a long
@@ -1227,10 +1113,12 @@ int gcn10_run(const gcn10_run_options *opt)
         }
         snprintf(msg, sizeof msg, "timing: %d blocks, %.3f s wall (%.3f s after start-up), %d gpu worker(s)%s%s%s; worker seconds: "
                  "in blocks %.3f, reading landcover %.3f, waiting for gpu %.3f, waiting for sink %.3f, "
-                 "soil window %.3f, creating outputs %.3f, finishing outputs %.3f, device setup %.3f",
+                 "soil window %.3f, creating outputs %.3f, finishing outputs %.3f, device setup %.3f, "
+                 "waiting for input %.3f; input thread seconds: %.3f%s",
                  done_blocks, now_seconds() - t_start, steady, r->n_workers, r->null_sink ? ", null sink" : "",
                  r->gpu_deflate ? (r->fused ? ", fused gpu deflate" : ", gpu deflate") : ", host zlib",
-                 r->gpu_inflate ? ", gpu inflate of deflate landcover" : "", busy, rd, gw, sw, so, cr, fi, dv);
+                 r->gpu_inflate ? ", gpu inflate of deflate landcover" : "", busy, rd, gw, sw, so, cr, fi, dv, iw, ib,
+                 r->prefetch ? " (one block ahead of the encoder)" : " (in turn with the encoder)");
         gcn10_log_message(log0, "INFO", msg, false);
         {
             /* CPU seconds of the whole process (all threads): against the wall time this says whether the host

@@ -18,9 +18,6 @@ struct run;
 
 /* one rotating set of strip buffers */
 struct strip_buf {
-    uint8_t *h_esa;                         /* pinned; these two only for blocks read on the host */
-    uint8_t *d_esa;
-    size_t esa_px;                          /* their capacity */
     uint8_t *h_out[GCN10_N_RASTERS];        /* pinned */
     uint8_t *d_out[GCN10_N_RASTERS];
     gcn10_event_t ev_h2d, ev_kernel, ev_d2h, ev_meta;
@@ -43,6 +40,38 @@ struct strip_buf {
     struct worker *owner;
 };
 
+/* One landcover block on its way from the files to the encoder.  Filled by the worker's input thread
+ * (pipeline_input.c) while the worker encodes the block before it: window arithmetic, soil window and index
+ * maps, the landcover window staged through pinned memory and decoded / untiled into d_block.  Everything in
+ * it belongs to the input thread while state == FILLING and to the worker while READY. */
+enum { IN_FREE = 0, IN_FILLING = 1, IN_READY = 2, IN_END = 3 };
+enum { N_IN = 2 };                          /* the block being encoded + the one being staged */
+enum { N_RING = 3 };                        /* pinned staging buffers of the input thread */
+
+struct block_in {
+    int state;                              /* IN_*; guarded by worker.in_mu */
+    int block_id;
+    int outcome;                            /* 0 = encode it; 1 = skipped (logged, like a failed load_raster,
+                                               src/cn.c:188-203); -1 = an error the reference answers with MPI_Abort */
+    int xoff, yoff, W, H, hsx, hsy;
+    double gt[6];
+    uint8_t *h_coarse;                      /* pinned: soil window, index maps */
+    int32_t *h_ci, *h_cj;
+    size_t h_coarse_cap, h_ci_cap, h_cj_cap;
+    uint8_t *d_coarse;
+    int32_t *d_ci, *d_cj;
+    size_t coarse_cap, ci_cap, cj_cap;
+    uint8_t *d_block;                       /* the landcover window, W x H, row major */
+    size_t block_cap;
+    uint8_t *d_comp;                        /* the window's chunks as they lie in the files (compressed or raw) */
+    size_t d_comp_cap;
+    gcn10_inflate_tile *h_jobs, *d_jobs;    /* h_jobs pinned */
+    uint32_t *h_status, *d_status;          /* h_status pinned */
+    size_t jobs_cap;
+    size_t n_inflate;                       /* chunks whose status must be looked at (0: host reader) */
+    gcn10_event_t ev_ready;                 /* recorded behind everything the block needs on the device */
+};
+
 struct worker {
     struct run *run;
     int rank;                               /* "rank" in the logs: outer_rank * n_workers + index */
@@ -50,40 +79,38 @@ struct worker {
     pthread_t thread;
     gcn10_log *log;
     gcn10_gpu_ctx *ctx;
-    gcn10_stream_t s_h2d, s_kernel, s_d2h;
+    gcn10_stream_t s_kernel, s_d2h;
     gcn10_raster *esa, *soil;
     size_t buf_px;                          /* capacity of one strip buffer, pixels */
     size_t buf_tiles;                       /* ... and in 256x256 tiles */
     int strip_rows;                         /* rows per strip of the current block */
     int n_cus;                              /* compute units of this worker's GPU */
     struct strip_buf buf[MAX_NBUF];         /* the first run->nbuf are in use */
-    uint8_t *h_coarse;                      /* pinned: soil window, index maps of the current block */
-    int32_t *h_ci, *h_cj;
-    size_t h_coarse_cap, h_ci_cap, h_cj_cap;
-    uint8_t *d_coarse;
-    size_t coarse_cap;
-    int32_t *d_ci, *d_cj;
-    size_t ci_cap, cj_cap;
     atomic_bool failed;                     /* a sink job of the current block failed */
     bool fused;                             /* this worker's tables allow the fused encoder */
-    /* landcover decoded on the GPU (gpu_inflate): the block's compressed chunks and where they go */
-    uint8_t *h_comp, *d_comp;               /* h_comp pinned */
-    size_t h_comp_cap, d_comp_cap;
-    gcn10_inflate_tile *h_jobs, *d_jobs;    /* h_jobs pinned */
-    uint32_t *h_status, *d_status;          /* h_status pinned */
-    size_t jobs_cap;
-    uint8_t *d_block;                       /* the decoded landcover block, W x H */
-    size_t block_cap;
-    gcn10_event_t ev_comp, ev_inflate;
-    size_t n_inflate;                       /* chunks of the block in flight */
+    /* input side: a thread of its own (prefetch_blocks=1) or the worker itself, in turn */
+    pthread_t in_thread;
+    bool in_thread_started;
+    gcn10_gpu_ctx *in_ctx;                  /* the input thread's own context on the same device */
+    gcn10_stream_t s_in;
+    struct block_in in[N_IN];
+    pthread_mutex_t in_mu;
+    pthread_cond_t in_cv;
+    bool in_stop;                           /* the worker is going away: the input thread must not wait for it */
+    uint8_t *h_ring[N_RING];                /* pinned: chunks (or host-decoded rows) on their way to the device */
+    size_t ring_cap;
+    gcn10_event_t ev_ring[N_RING];
+    bool ring_busy[N_RING];
     int blocks_done;
+    int in_seq;                             /* blocks taken from the input side so far: slot = in_seq % N_IN */
     int device;                             /* the GPU this worker drives */
     int numa_node;                          /* ... and the NUMA node it hangs off (-1 = unknown) */
     char pci_bus[64];
     double busy_seconds;
     double t_first_block;                   /* when this worker started its first block */
-    double t_read, t_gpu_wait, t_sink_wait;            /* where the worker thread's time goes */
-    double t_soil, t_create, t_finish, t_device;
+    double t_gpu_wait, t_sink_wait;         /* where the worker thread's time goes */
+    double t_create, t_finish, t_device, t_in_wait;
+    double t_read, t_soil, t_in_busy;       /* ... and the input thread's */
 };
 
 struct run {
@@ -106,6 +133,8 @@ struct run {
     bool gpu_deflate;                       /* tiles are encoded on the GPU */
     bool fused;                             /* ... straight from landcover + soil (no CN rasters in HBM) */
     bool gpu_inflate;                       /* DEFLATE landcover tiles are decoded on the GPU */
+    bool direct_io;                         /* tile data is written with O_DIRECT */
+    bool prefetch;                          /* input threads stage block N+1 while block N is encoded */
     int n_devices;                          /* visible GPUs; worker i uses device i % n_devices */
     int outer_rank, outer_size;             /* this process among the processes of an mpirun / srun */
     unsigned cond_mask, table_mask;         /* the rasters this run produces ("conditions" / "lookups") */
@@ -116,13 +145,22 @@ struct run {
 double gcn10_now_seconds(void);
 void gcn10_wlog(struct worker *w, const char *level, bool console, const char *fmt, ...)
     __attribute__((format(printf, 4, 5)));
-/* device buffer of at least `need` bytes (grown by reallocation); -1 and a log line on failure */
-int gcn10_ensure_dev(struct worker *w, void **p, size_t *cap, size_t need);
 
-/* pipeline_input.c: landcover window of a block -> w->d_block through the GPU decoder.
- * 0 = issued on s_kernel (statuses arrive with ev_inflate), 1 = this window needs the host
- * reader, -1 = the window cannot be read or decoded (logged; the block is skipped as after a failed
- * load_raster, src/cn.c:188-192), -2 = device error (logged; fatal for the run). */
-int gcn10_inflate_block(struct worker *w, int xoff, int yoff, int W, int H, int block_id);
+/* device / pinned buffer of at least `need` bytes on context `ctx` (grown by reallocation); -1 and a log line on failure */
+int gcn10_ensure_dev_on(struct worker *w, gcn10_gpu_ctx *ctx, void **p, size_t *cap, size_t need);
+int gcn10_ensure_pinned_on(struct worker *w, gcn10_gpu_ctx *ctx, void **p, size_t *cap, size_t need);
+
+/* pipeline_input.c: the input side of a worker.
+ * gcn10_input_setup / _teardown: context, stream, events, pinned ring of the input side.
+ * gcn10_input_start: starts the input thread (prefetch) -- it takes block ids from the run's counter, fills
+ *   w->in[] slots in turn and marks them IN_READY (IN_END after the last one).
+ * gcn10_input_next: the slot the worker encodes next (waits for it; without a thread, fills it right here);
+ *   NULL at the end of the queue.  gcn10_input_release hands the slot back. */
+int gcn10_input_setup(struct worker *w);
+void gcn10_input_teardown(struct worker *w);
+int gcn10_input_start(struct worker *w);
+struct block_in *gcn10_input_next(struct worker *w);
+void gcn10_input_release(struct worker *w, struct block_in *in);
+void gcn10_input_stop(struct worker *w);
 
 #endif

@@ -732,12 +732,18 @@ int gcn10_tiff_read_window(struct gcn10_tiff *t, int xoff, int yoff, int xcount,
     return gcn10_tiff_read_window_mt(t, xoff, yoff, xcount, ycount, dst, dst_stride, NULL, err, errcap);
 }
 
-/* The chunks of a window as they lie in the file, for the GPU decoder.  Mirrors the
- * clipping of read_chunk(). */
+/* The chunks of a window as they lie in the file, for the GPU side: DEFLATE chunks are inflated
+ * there, uncompressed chunks are only untiled there, and TIFF predictor 2 (horizontal differencing)
+ * is undone there in either case.  LZW and PackBits stay with the host reader (return 1).  Mirrors
+ * the clipping of read_chunk().  Of an uncompressed chunk only the bytes from the first wanted pixel
+ * to the last wanted pixel are staged. */
 int gcn10_tiff_plan_window(struct gcn10_tiff *t, int xoff, int yoff, int xcount, int ycount, int dst_x,
                            int dst_y, struct gcn10_read_plan *plan, char *err, size_t errcap)
 {
-    if ((t->compression != 8 && t->compression != 32946) || t->predictor == 2 || t->spp != 1 ||
+    const bool raw = t->compression == 1;
+    const bool deflate = t->compression == 8 || t->compression == 32946;
+
+    if ((!raw && !deflate) || (t->predictor != 1 && t->predictor != 2) || t->spp != 1 ||
         t->bps != 8 || (uint64_t)t->cw * t->ch > ((uint64_t)1 << 28))
         return 1;
     if (xoff < 0 || yoff < 0 || xcount <= 0 || ycount <= 0 ||
@@ -778,7 +784,7 @@ int gcn10_tiff_plan_window(struct gcn10_tiff *t, int xoff, int yoff, int xcount,
                 plan->chunks = g;
                 plan->cap = cap;
             }
-            c = &plan->chunks[plan->n++];
+            c = &plan->chunks[plan->n];
             c->fd = t->fd;
             c->file_off = off;
             c->nbytes = (uint32_t)cnt;
@@ -790,9 +796,36 @@ int gcn10_tiff_plan_window(struct gcn10_tiff *t, int xoff, int yoff, int xcount,
             c->copy_h = ye - ys;
             c->dst_x = (uint32_t)dst_x + (xs - (uint32_t)xoff);
             c->dst_y = (uint32_t)dst_y + (ys - (uint32_t)yoff);
-            plan->covered += (uint64_t)c->copy_w * c->copy_h;
-            if (t->cw * rows > plan->max_chunk_bytes)
+            /* (the Predictor tag belongs to the LZW / DEFLATE codecs: libtiff, and with it GDAL, ignores it on
+             * uncompressed data, and so does decode_chunk()) */
+            c->flags = raw ? GCN10_TILE_RAW : (t->predictor == 2 ? GCN10_TILE_PREDICTOR2 : 0u);
+            c->out_len = t->cw * rows;
+            if (raw) {
+                /* the bytes that matter: from the first wanted pixel to the last one */
+                const uint64_t first = (uint64_t)c->src_y * t->cw + c->src_x;
+                const uint64_t last = (uint64_t)(c->src_y + c->copy_h - 1u) * t->cw + c->src_x + c->copy_w;
+
+                if (cnt < last) {       /* a chunk shorter than its pixels: what decode_chunk() refuses */
+                    snprintf(err, errcap, "gdalrasterio error: cannot decode a %s of the window %d,%d %dx%d",
+                             t->tiled ? "tile" : "strip", xoff, yoff, xcount, ycount);
+                    return -1;
+                }
+                /* full-width strips of a raster much wider than the window: most staged bytes would be
+                 * other blocks' pixels -- the host reader copies rows instead */
+                if (last - first > 4u * (uint64_t)c->copy_w * c->copy_h + ((uint64_t)1 << 20))
+                    return 1;
+                c->file_off = off + first;
+                c->nbytes = (uint32_t)(last - first);
+                c->out_len = c->nbytes;
+                c->src_y = 0;
+                c->src_x = 0;
+            }
+            else if (t->cw * rows > plan->max_chunk_bytes) {
                 plan->max_chunk_bytes = t->cw * rows;
+            }
+            plan->n++;
+            plan->staged_bytes += c->nbytes;
+            plan->covered += (uint64_t)c->copy_w * c->copy_h;
         }
     }
     return 0;
@@ -815,6 +848,7 @@ struct gcn10_tiff_writer {
     uint64_t pos;               /* append position */
     pthread_mutex_t mu;
     bool failed;
+    bool direct;                /* O_DIRECT is set on fd: extents go out at 4096-aligned positions */
 };
 
 static int write_all(int fd, const void *buf, size_t n, uint64_t off)
@@ -1024,6 +1058,83 @@ int gcn10_tiff_put_tiles(gcn10_tiff_writer *w, int n, const int *tx, const int *
     return rc;
 }
 
+/* O_DIRECT for the tile data of this file (the directory is written without it at the end).  Extents
+ * handed to gcn10_tiff_put_extent must then start at 4096-aligned addresses and be readable up to the
+ * next multiple of 4096 past their end -- the pinned copy of the GPU encoder's arena is
+ * (DIRECT_ALIGN = the encoder's "arena_segment_align").  A file system that refuses the flag leaves the
+ * writer as it was: returns 0 when direct I/O is on, -1 when it is not. */
+enum { DIRECT_ALIGN = 4096 };
+
+int gcn10_tiff_set_direct(gcn10_tiff_writer *w, bool on)
+{
+    int fl = fcntl(w->fd, F_GETFL);
+
+    if (fl < 0)
+        return -1;
+    if (on == w->direct)
+        return on ? 0 : -1;
+#ifdef O_DIRECT
+    if (fcntl(w->fd, F_SETFL, on ? (fl | O_DIRECT) : (fl & ~O_DIRECT)) != 0)
+        return -1;
+    w->direct = on;
+    return on ? 0 : -1;
+#else
+    return -1;
+#endif
+}
+
+/* n tiles of the raster whose streams lie in ONE extent of memory, `extent_bytes` long, stream i at
+ * rel_off[i] (the layout the GPU encoders produce: a raster's streams of a strip back to back in tile order):
+ * one write for all of them.  Same file contents as n gcn10_tiff_put_tile calls except for the few
+ * alignment bytes between streams, which no directory entry points at. */
+int gcn10_tiff_put_extent(gcn10_tiff_writer *w, const void *data, size_t extent_bytes, int n, const int *tx,
+                          const int *ty, const uint32_t *rel_off, const uint32_t *nbytes)
+{
+    int rc = 0;
+
+    for (int i = 0; i < n; i++)
+        if (tx[i] < 0 || ty[i] < 0 || tx[i] >= w->across || ty[i] >= w->down || nbytes[i] == 0 ||
+            (size_t)rel_off[i] + nbytes[i] > extent_bytes)
+            return -1;
+    pthread_mutex_lock(&w->mu);
+    {
+        uint64_t at = w->pos;
+        size_t len = extent_bytes;
+
+        if (w->direct) {
+            at = (at + DIRECT_ALIGN - 1) / DIRECT_ALIGN * DIRECT_ALIGN;
+            len = (len + DIRECT_ALIGN - 1) / DIRECT_ALIGN * DIRECT_ALIGN;
+        }
+        if (at + len + (1u << 20) > 0xffffffffull) {
+            rc = -1;                    /* classic TIFF offsets are 32 bit */
+        }
+        else if (write_all(w->fd, data, len, at) != 0) {
+            if (w->direct && errno == EINVAL && gcn10_tiff_set_direct(w, false) != 0 && !w->direct) {
+                /* this file system takes the flag and then refuses the write: once more without it */
+                at = w->pos;
+                len = extent_bytes;
+                rc = write_all(w->fd, data, len, at) != 0 ? -1 : 0;
+            }
+            else {
+                rc = -1;
+            }
+        }
+        if (rc == 0) {
+            for (int i = 0; i < n; i++) {
+                size_t idx = (size_t)ty[i] * (size_t)w->across + (size_t)tx[i];
+
+                w->offsets[idx] = (uint32_t)(at + rel_off[i]);
+                w->counts[idx] = nbytes[i];
+            }
+            w->pos = at + len;
+        }
+    }
+    if (rc != 0)
+        w->failed = true;
+    pthread_mutex_unlock(&w->mu);
+    return rc;
+}
+
 static void put16(unsigned char *p, unsigned v)
 {
     p[0] = (unsigned char)(v & 0xff);
@@ -1063,6 +1174,8 @@ int gcn10_tiff_finish(gcn10_tiff_writer *w, char *err, size_t errcap)
         snprintf(err, errcap, "write error on %s", w->path);
         goto done;
     }
+    if (w->direct)
+        gcn10_tiff_set_direct(w, false);        /* the directory is not sector sized */
     for (size_t i = 0; i < nt; i++)
         if (w->counts[i] == 0) {
             snprintf(err, errcap, "write error on %s: tile %zu was never written", w->path, i);

@@ -47,9 +47,10 @@ ABI_SYMBOLS = (
 
 
 # struct gcn10_inflate_tile (include/gcn10_gpu.h)
+TILE_RAW, TILE_PREDICTOR2 = 1, 2          # gcn10_inflate_tile.flags (include/gcn10_gpu.h)
 INFLATE_TILE_DTYPE = np.dtype([("in_off", "<u8"), ("in_len", "<u4"), ("out_len", "<u4"), ("chunk_w", "<u4"),
                                ("src_x", "<u4"), ("src_y", "<u4"), ("copy_w", "<u4"), ("copy_h", "<u4"),
-                               ("reserved", "<u4"), ("dst_off", "<u8")])
+                               ("flags", "<u4"), ("dst_off", "<u8")])
 
 
 class Gcn10GpuError(RuntimeError):
@@ -386,19 +387,23 @@ class Engine:
         return data, tab, used
 
     def inflate_tiles(self, streams: Sequence[bytes], chunk_w: int, chunk_rows: Sequence[int],
-                      windows: Sequence[tuple], dst_shape: tuple, stream=None):
+                      windows: Sequence[tuple], dst_shape: tuple, stream=None, flags: Optional[Sequence[int]] = None,
+                      out_lens: Optional[Sequence[int]] = None):
         """Decodes zlib streams on the GPU (gcn10_gpu_inflate_tiles).
 
         streams[i] decodes to a chunk of chunk_rows[i] x chunk_w pixels; windows[i] =
         (src_x, src_y, copy_w, copy_h, dst_x, dst_y) places part of it in a zero-filled uint8
-        raster of dst_shape.  Returns (raster, status uint32[n])."""
+        raster of dst_shape.  flags[i]: TILE_RAW (streams[i] is the chunk's pixels as they are) |
+        TILE_PREDICTOR2 (rows are horizontal differences); out_lens[i] overrides the decoded size
+        (a raw chunk staged from its first wanted row on).  Returns (raster, status uint32[n])."""
         n = len(streams)
         H, W = dst_shape
         tiles = np.zeros(n, dtype=INFLATE_TILE_DTYPE)
         parts, off = [], 0
         for k, st in enumerate(streams):
             sx, sy, cw, ch, dx, dy = windows[k]
-            tiles[k] = (off, len(st), chunk_w * chunk_rows[k], chunk_w, sx, sy, cw, ch, 0, dy * W + dx)
+            tiles[k] = (off, len(st), out_lens[k] if out_lens else chunk_w * chunk_rows[k], chunk_w, sx, sy, cw, ch,
+                        flags[k] if flags else 0, dy * W + dx)
             pad = (-len(st)) % 16 + 16
             parts.append(st)
             parts.append(bytes(pad))

@@ -85,7 +85,8 @@ class Config(C.Structure):
                 ("log_dir", C.c_char_p), ("gpus", C.c_int), ("workers_per_gpu", C.c_int),
                 ("strip_rows", C.c_int),
                 ("io_threads", C.c_int), ("deflate_level", C.c_int), ("esa_tile_dir", C.c_char_p),
-                ("gpu_deflate", C.c_int), ("gpu_inflate", C.c_int),
+                ("gpu_deflate", C.c_int), ("gpu_inflate", C.c_int), ("direct_io", C.c_int),
+                ("prefetch_blocks", C.c_int),
                 ("table_mask", C.c_uint), ("cond_mask", C.c_uint)]
 
 
@@ -152,14 +153,15 @@ class _ChunkRef(C.Structure):
     """``struct gcn10_chunk_ref`` of csrc/host/host_internal.h."""
     _fields_ = [("fd", C.c_int), ("file_off", C.c_uint64), ("nbytes", C.c_uint32), ("chunk_w", C.c_uint32),
                 ("rows", C.c_uint32), ("src_x", C.c_uint32), ("src_y", C.c_uint32), ("copy_w", C.c_uint32),
-                ("copy_h", C.c_uint32), ("dst_x", C.c_uint32), ("dst_y", C.c_uint32)]
+                ("copy_h", C.c_uint32), ("dst_x", C.c_uint32), ("dst_y", C.c_uint32), ("flags", C.c_uint32),
+                ("out_len", C.c_uint32)]
 
 
 class _ReadPlan(C.Structure):
     """``struct gcn10_read_plan`` of csrc/host/host_internal.h."""
     _fields_ = [("chunks", C.POINTER(_ChunkRef)), ("n", C.c_size_t), ("cap", C.c_size_t),
                 ("opened", C.c_void_p), ("n_opened", C.c_int), ("covered", C.c_uint64),
-                ("max_chunk_bytes", C.c_uint32)]
+                ("max_chunk_bytes", C.c_uint32), ("staged_bytes", C.c_uint64)]
 
 
 class Raster:
@@ -210,7 +212,7 @@ class Raster:
                 c = plan.chunks[i]
                 chunks.append({"data": os.pread(c.fd, c.nbytes, c.file_off), "chunk_w": c.chunk_w, "rows": c.rows,
                                "src_x": c.src_x, "src_y": c.src_y, "copy_w": c.copy_w, "copy_h": c.copy_h,
-                               "dst_x": c.dst_x, "dst_y": c.dst_y})
+                               "dst_x": c.dst_x, "dst_y": c.dst_y, "flags": c.flags, "out_len": c.out_len})
             return chunks, plan.covered, plan.max_chunk_bytes
         finally:
             L.gcn10_read_plan_free(C.byref(plan))

@@ -30,7 +30,11 @@
 extern "C" {
 #endif
 
-#define GCN10_GPU_ABI_VERSION 1
+/* 1: round 1.  2: + gcn10_gpu_tune_single_raster, gcn10_gpu_stream_copy, gcn10_gpu_soil_words_state (round 2).
+ * 3: gcn10_inflate_tile.reserved became .flags (raw and predictor-2 chunks), the tile encoders lay a raster's
+ *    streams of a strip out as one extent (option "arena_segment_align"), gcn10_gpu_deflate_arena_bound grew by
+ *    the extents' pads (round 3).  A caller built against an older header must be rebuilt: check at start-up. */
+#define GCN10_GPU_ABI_VERSION 3
 
 enum {
     GCN10_OK = 0,
@@ -228,9 +232,17 @@ typedef struct gcn10_inflate_tile {
     uint32_t chunk_w;       /* pixels per row of the decoded chunk */
     uint32_t src_x, src_y;  /* first wanted pixel of the chunk */
     uint32_t copy_w, copy_h;
-    uint32_t reserved;
+    uint32_t flags;         /* GCN10_TILE_* (ABI 3; 0 = a zlib stream, no predictor, as in ABI 1-2) */
     uint64_t dst_off;       /* where pixel (src_x, src_y) goes in dst_dev */
 } gcn10_inflate_tile;
+/* flags: RAW = the chunk is not compressed (TIFF Compression 1): in_len >= out_len bytes of pixels lie at
+ * in_off and only the window copy is done (no alignment rule for in_off; the host may stage only the bytes
+ * from the first wanted pixel on: src_x = src_y = 0 then, chunk_w still the chunk's row pitch).
+ * PREDICTOR2 = the chunk was written with TIFF Predictor 2 (horizontal differencing): every chunk row is
+ * summed back, byte-wise modulo 256, from the row's first pixel while it is copied (tiff.c decode_chunk does
+ * the same on the host). */
+#define GCN10_TILE_RAW 1u
+#define GCN10_TILE_PREDICTOR2 2u
 enum {
     GCN10_INFLATE_E_HEADER = 1, GCN10_INFLATE_E_BLOCK_TYPE = 2, GCN10_INFLATE_E_STORED = 3,
     GCN10_INFLATE_E_LENGTHS = 4, GCN10_INFLATE_E_CODE = 5, GCN10_INFLATE_E_DISTANCE = 6,

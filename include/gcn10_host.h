@@ -100,7 +100,12 @@ typedef struct gcn10_config {
                                1 = CN strips in HBM, then encoded on the GPU per raster;
                                0 = raw strips are copied back, host zlib threads encode */
     int gpu_inflate;        /* "gpu_inflate": 1 (default) DEFLATE-compressed landcover tiles cross PCIe
-                               compressed and are decoded on the GPU; 0 = on the host i/o pool */
+                               compressed and are decoded on the GPU, uncompressed ones are untiled there,
+                               TIFF predictor 2 is undone there; 0 = all of it on the host i/o pool */
+    int direct_io;          /* "direct_io": 1 = the GeoTIFFs' tile data is written with O_DIRECT from the pinned
+                               copy of the encoder's arena (no page-cache copy); 0 (default) = buffered writes */
+    int prefetch_blocks;    /* "prefetch_blocks": 1 (default) = every block worker has an input thread that stages
+                               and decodes the NEXT block's landcover while this one is encoded; 0 = in turn */
     unsigned table_mask;    /* "lookups": which of the nine lookups to produce, e.g. "g_ii" or "p_i,f_iii"
                                ("all" / absent = all nine); bit k = hc*3 + arc in the reference's loop
                                order p,f,g x i,ii,iii (src/cn.c:146-147) */
@@ -191,6 +196,13 @@ int gcn10_tiff_put_tile(gcn10_tiff_writer *w, int tx, int ty, const void *zdata,
 /* n tiles of the raster in one go (gathered writes); same result as n gcn10_tiff_put_tile calls */
 int gcn10_tiff_put_tiles(gcn10_tiff_writer *w, int n, const int *tx, const int *ty,
                          const void *const *zdata, const uint32_t *nbytes);
+/* n tiles whose streams lie in one extent of memory (stream i at data + rel_off[i]): one write for all of
+ * them.  What the GPU encoders produce for a raster and a strip. */
+int gcn10_tiff_put_extent(gcn10_tiff_writer *w, const void *data, size_t extent_bytes, int n, const int *tx,
+                          const int *ty, const uint32_t *rel_off, const uint32_t *nbytes);
+/* O_DIRECT for the tile data (config key "direct_io"): extents must then be 4096-aligned in memory and
+ * readable to the next multiple of 4096.  0 = on, -1 = the file system refuses (nothing changed). */
+int gcn10_tiff_set_direct(gcn10_tiff_writer *w, bool on);
 /* Writes the directory and closes the file.  0 or -1. */
 int gcn10_tiff_finish(gcn10_tiff_writer *w, char *err, size_t errcap);
 void gcn10_tiff_abort(gcn10_tiff_writer *w);

@@ -468,11 +468,23 @@ static void do_inflate(void *a)
 
     for (int i = 0; i < o->n; i++) {
         const gcn10_inflate_tile *t = &o->tiles[i];
-        uint8_t *tmp = calloc(1, t->out_len ? t->out_len : 1);
+        uint8_t *tmp = calloc(1, (size_t)(t->out_len ? t->out_len : 1) + t->chunk_w);
         uLongf len = t->out_len;
-        int rc = tmp ? uncompress(tmp, &len, o->comp + t->in_off, t->in_len) : Z_MEM_ERROR;
+        int rc = Z_MEM_ERROR;
 
+        if (tmp && (t->flags & GCN10_TILE_RAW)) {
+            rc = t->in_len >= t->out_len ? Z_OK : Z_DATA_ERROR;
+            if (rc == Z_OK)
+                memcpy(tmp, o->comp + t->in_off, t->out_len);
+        }
+        else if (tmp) {
+            rc = uncompress(tmp, &len, o->comp + t->in_off, t->in_len);
+        }
         o->status[i] = (rc == Z_OK || rc == Z_BUF_ERROR) ? 0 : GCN10_INFLATE_E_CODE;
+        if (tmp && (t->flags & GCN10_TILE_PREDICTOR2) && t->chunk_w)
+            for (size_t r0 = 0; r0 < t->out_len; r0 += t->chunk_w)          /* per chunk row, from its first byte */
+                for (size_t x = 1; x < t->chunk_w && r0 + x < t->out_len; x++)
+                    tmp[r0 + x] = (uint8_t)(tmp[r0 + x] + tmp[r0 + x - 1]);
         for (uint32_t y = 0; tmp && y < t->copy_h; y++)
             memcpy(o->dst + t->dst_off + (size_t)y * o->stride, tmp + (size_t)(t->src_y + y) * t->chunk_w + t->src_x,
                    t->copy_w);

@@ -25,7 +25,7 @@ def test_gpu_library_exports_every_declared_symbol():
     L = gpu.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.gcn10_gpu_abi_version() == 1
+    assert L.gcn10_gpu_abi_version() == 3
 
 
 def test_host_library_exports_every_declared_symbol():

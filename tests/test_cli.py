@@ -314,6 +314,89 @@ def test_deflate_landcover_decoded_on_the_gpu_or_the_host(tmp_path, tables, gpu_
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["raw-tiles", "raw-strips", "deflate-predictor2-tiles", "deflate-predictor2-strips",
+                                  "lzw-predictor2-tiles"])
+@pytest.mark.parametrize("prefetch", [1, 0], ids=["one-block-ahead", "in-turn"])
+def test_raw_and_predictor2_landcover_through_the_gpu_side(tmp_path, tables, kind, prefetch):
+    """Round 3: uncompressed landcover (the literal path of the north star: raw bytes -> pinned ring ->
+    hipMemcpyAsync -> HBM, untiled there) and DEFLATE landcover written with TIFF predictor 2 (summed back on
+    the GPU) give the oracle's rasters; LZW stays with the host reader and gives them too.  Both with the
+    input thread one block ahead of the encoder and with input and encode in turn."""
+    esa, soil = _world(tmp_path, seed=81, extra_cfg="prefetch_blocks=%d\n" % prefetch)
+    kw = {"raw-tiles": dict(compression=1, tile=(256, 128)), "raw-strips": dict(compression=1, rows_per_strip=16),
+          "deflate-predictor2-tiles": dict(compression=8, predictor=2, tile=(512, 512)),
+          "deflate-predictor2-strips": dict(compression=8, predictor=2, rows_per_strip=37),
+          "lzw-predictor2-tiles": dict(compression=5, predictor=2, tile=(256, 256))}[kind]
+    tiffutil.write_tiff(str(tmp_path / "esa.tif"), esa, gt=ESA_GT, **kw)
+    (tmp_path / "ids.txt").write_text("101 102 103\n")
+    out = _run(tmp_path, "-c", "config.txt", "-l", "ids.txt")
+    assert out.returncode == 0, out.stderr[-2000:]
+    log = (tmp_path / "logs" / "rank_0.log").read_text()
+    assert ("one block ahead of the encoder" in log) == bool(prefetch)
+    for bid, *bbox in BLOCKS[:3]:
+        _check_block(tmp_path, esa, soil, tables, bid, bbox, rasters=(0, 4, 8, 9, 13, 17))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("predictor", [1, 2])
+def test_vrt_of_cog_shaped_landcover_tiles(tmp_path, tables, predictor):
+    """The landcover as the shipped VRT names it (/root/reference/landcover/esa_worldcover_2021.vrt:265-272): a
+    mosaic of cloud-optimised GeoTIFFs -- full-resolution IFD first, two overview IFDs behind it, tile data laid
+    out overviews first, 1024 x 1024 DEFLATE blocks, with and without predictor 2 -- resolved through
+    esa_tile_dir; the block's window crosses the seam between the two files.  The reader must take IFD 0's
+    tiles, the GPU plan must accept them."""
+    from gcn10_amd import host
+    rng = np.random.default_rng(41)
+    small = rng.choice(ESA_NASTY, size=(2000 // 16, 3000 // 16))
+    esa = np.repeat(np.repeat(small, 16, axis=0), 16, axis=1)
+    esa = np.where(rng.random(esa.shape) < 0.1, rng.choice(ESA_NASTY, size=esa.shape), esa).astype(np.uint8)
+    esa[esa == 0] = 10
+    soil = rng.choice(HSG_NASTY, size=(82, 122)).astype(np.uint8)
+    (tmp_path / "tiles").mkdir()
+    tiffutil.write_cog(str(tmp_path / "tiles" / "C_W.tif"), esa[:, :1536], tile=(1024, 1024), overviews=2, predictor=predictor)
+    tiffutil.write_cog(str(tmp_path / "tiles" / "C_E.tif"), esa[:, 1536:], tile=(1024, 1024), overviews=2, predictor=predictor)
+    src = ""
+    for name, dx, w in (("C_W.tif", 0, 1536), ("C_E.tif", 1536, 1464)):
+        src += ('<ComplexSource resampling="nearest"><SourceFilename relativeToVRT="0">/vsicurl/https://example.invalid/'
+                'map/%s</SourceFilename><SourceBand>1</SourceBand><SrcRect xOff="0" yOff="0" xSize="%d" ySize="2000" />'
+                '<DstRect xOff="%d" yOff="0" xSize="%d" ySize="2000" /><NODATA>0</NODATA></ComplexSource>\n'
+                % (name, w, dx, w))
+    (tmp_path / "esa.vrt").write_text(
+        '<VRTDataset rasterXSize="3000" rasterYSize="2000">\n<GeoTransform> %r, %r, 0.0, %r, 0.0, %r</GeoTransform>\n'
+        '<VRTRasterBand dataType="Byte" band="1"><NoDataValue>0</NoDataValue>\n%s</VRTRasterBand></VRTDataset>\n'
+        % (ESA_GT[0], ESA_GT[1], ESA_GT[3], ESA_GT[5], src))
+    # the plan exists (the GPU side takes these files) and names full-resolution chunks only
+    with host.Raster(str(tmp_path / "esa.vrt"), str(tmp_path / "tiles")) as r:
+        plan = r.plan(1000, 500, 1000, 1000)
+        assert plan is not None and plan[1] == 1000 * 1000
+        assert all(c["chunk_w"] == 1024 and c["flags"] == (2 if predictor == 2 else 0) for c in plan[0])
+        assert np.array_equal(r.read(1000, 500, 1000, 1000), esa[500:1500, 1000:2000])
+    tiffutil.write_tiff(str(tmp_path / "soil.tif"), soil, gt=SOIL_GT, compression=5, rows_per_strip=8)
+    tiffutil.write_block_shapefile(str(tmp_path / "blocks"), [(7, 11.0, 48.5, 12.0, 49.5)])
+    (tmp_path / "config.txt").write_text(
+        "hysogs_data_path=%s\nesa_data_path=%s\nblocks_shp_path=%s\nlookup_table_path=%s\nlog_dir=%s\n"
+        "esa_tile_dir=%s\nstrip_rows=512\n" % (tmp_path / "soil.tif", tmp_path / "esa.vrt", tmp_path / "blocks.shp",
+                                               LOOKUPS, tmp_path / "logs", tmp_path / "tiles"))
+    out = _run(tmp_path, "-c", "config.txt")
+    assert out.returncode == 0, out.stderr[-2000:]
+    _check_block(tmp_path, esa, soil, tables, 7, [11.0, 48.5, 12.0, 49.5], rasters=(0, 5, 9, 17))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("direct", [0, 1])
+def test_one_extent_per_raster_and_strip_with_and_without_direct_io(tmp_path, tables, direct):
+    """Round 3: the encoder lays a raster's streams of a strip out as one extent (pass B'), the sink appends it
+    with one write -- buffered, or with O_DIRECT (direct_io=1) where the file system takes it (it falls back
+    where it does not, e.g. tmpfs).  Same decoded rasters, same tags."""
+    esa, soil = _world(tmp_path, seed=55, extra_cfg="direct_io=%d\n" % direct)
+    (tmp_path / "ids.txt").write_text("101 103\n")
+    out = _run(tmp_path, "-c", "config.txt", "-l", "ids.txt")
+    assert out.returncode == 0, out.stderr[-2000:]
+    for bid, *bbox in (BLOCKS[0], BLOCKS[2]):
+        _check_block(tmp_path, esa, soil, tables, bid, bbox)
+
+
+@pytest.mark.gpu
 def test_vrt_of_deflate_tiles_with_a_gap_decodes_on_the_gpu(tmp_path, tables):
     """A mosaic of two DEFLATE tiles that leaves a strip of the block uncovered: the chunks of both
     files are decoded on the GPU, the gap reads as 0 (the VRT's NoDataValue)."""

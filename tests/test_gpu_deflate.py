@@ -93,8 +93,8 @@ def test_argument_errors(engine):
     from gcn10_amd import gpu
     with pytest.raises(gpu.Gcn10GpuError):
         engine.deflate_rasters([], 256, 256)
-    assert gpu.lib().gcn10_gpu_deflate_arena_bound(256, 256, 1) == 65552
-    assert gpu.lib().gcn10_gpu_deflate_arena_bound(257, 256, 2) == 4 * 65552
+    assert gpu.lib().gcn10_gpu_deflate_arena_bound(256, 256, 1) == 65552 + 4096      # + the pad that brings a raster's extent to a multiple of 4096 (round 3)
+    assert gpu.lib().gcn10_gpu_deflate_arena_bound(257, 256, 2) == 4 * 65552 + 2 * 4096
     assert gpu.lib().gcn10_gpu_deflate_arena_bound(0, 256, 1) == 0
 
 

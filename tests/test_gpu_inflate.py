@@ -146,6 +146,59 @@ def test_many_tiles_with_windows(engine):
     assert np.array_equal(out, world[y0:y0 + H, x0:x0 + W])
 
 
+def test_raw_and_predictor2_tiles_mixed_with_deflate_ones(engine):
+    """Round 3 (ABI 3, gcn10_inflate_tile.flags): uncompressed chunks are untiled from the staged bytes --
+    whole, or staged from the first wanted pixel on --, and chunks written with TIFF predictor 2 are summed
+    back row by row, modulo 256, from each row's first pixel (tiff.c decode_chunk is the host form).  One
+    launch holds all four kinds; chunk widths that are and are not multiples of the 1024-byte trip."""
+    rng = np.random.default_rng(21)
+    for tw, th in ((256, 200), (1024, 64), (1500, 9), (37, 50)):
+        nx, ny = 5, 4
+        world = np.zeros((ny * th, nx * tw), np.uint8)
+        x0, y0, W, H = tw // 3, 7, nx * tw - tw // 2 - 11, ny * th - 13
+        streams, rows, wins, flags, out_lens = [], [], [], [], []
+        for ty in range(ny):
+            for tx in range(nx):
+                kind = ["classes", "noise", "patches", "skewed"][(tx + 2 * ty) % 4]
+                t = _data(kind, tw * th, seed=tx * 10 + ty).reshape(th, tw)
+                world[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw] = t
+                xs, xe = max(x0, tx * tw), min(x0 + W, (tx + 1) * tw)
+                ys, ye = max(y0, ty * th), min(y0 + H, (ty + 1) * th)
+                sx, sy, cw, ch = xs - tx * tw, ys - ty * th, xe - xs, ye - ys
+                diff = t.astype(np.int16)
+                diff[:, 1:] -= t[:, :-1].astype(np.int16)
+                diff = (diff & 0xFF).astype(np.uint8)
+                mode = (tx + ty) % 4
+                if mode == 0:                               # DEFLATE, no predictor (ABI 1 behaviour)
+                    streams.append(_compress(t.reshape(-1), int(rng.integers(1, 10))))
+                    flags.append(0)
+                    out_lens.append(tw * th)
+                elif mode == 1:                             # DEFLATE + predictor 2
+                    streams.append(_compress(diff.reshape(-1), 6))
+                    flags.append(gpu.TILE_PREDICTOR2)
+                    out_lens.append(tw * th)
+                elif mode == 2:                             # raw, the whole chunk staged
+                    streams.append(t.tobytes())
+                    flags.append(gpu.TILE_RAW)
+                    out_lens.append(tw * th)
+                else:                                       # raw, staged from the first wanted pixel to the last
+                    flat = t.reshape(-1)
+                    first, last = sy * tw + sx, (sy + ch - 1) * tw + sx + cw
+                    streams.append(flat[first:last].tobytes())
+                    flags.append(gpu.TILE_RAW)
+                    out_lens.append(last - first)
+                    sx, sy = 0, 0
+                rows.append(th)
+                wins.append((sx, sy, cw, ch, xs - x0, ys - y0))
+        out, status = engine.inflate_tiles(streams, tw, rows, wins, (H, W), flags=flags, out_lens=out_lens)
+        assert not status.any(), (tw, th, status)
+        assert np.array_equal(out, world[y0:y0 + H, x0:x0 + W]), (tw, th)
+    # a raw chunk shorter than its window is refused, not read past
+    out, status = engine.inflate_tiles([bytes(100)], 20, [10], [(0, 0, 20, 10, 0, 0)], (10, 20), flags=[gpu.TILE_RAW],
+                                       out_lens=[200])
+    assert int(status[0]) == 8 and not out.any()
+
+
 def test_full_size_tiles_of_a_block_row(engine):
     # 36 tiles of 1024 x 1024, the shape of one tile row of an ESA WorldCover file
     tiles = [_data(["patches", "classes"][k % 2], 1 << 20, seed=k) for k in range(36)]

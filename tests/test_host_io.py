@@ -293,14 +293,30 @@ def test_save_raster_errors(tmp_path):
 # ---- read plans for the GPU decoder (csrc/host/raster.c, tiff.c) ----------------------------
 
 def _assemble(plan, W, H):
+    """What gcn10_gpu_inflate_tiles is asked to do with a plan, done here with stock zlib and numpy: DEFLATE
+    chunks inflate to chunk_w x rows pixels; raw chunks ARE out_len bytes of pixels, staged from the first
+    wanted row (and, without a predictor, the first wanted pixel) on; predictor 2 sums every chunk row."""
     import zlib
     chunks, covered, max_bytes = plan
     out = np.zeros((H, W), np.uint8)
     seen = 0
     for c in chunks:
-        raw = np.frombuffer(zlib.decompress(c["data"]), np.uint8)
-        assert raw.size >= c["chunk_w"] * c["rows"] and c["chunk_w"] * c["rows"] <= max_bytes
-        t = raw[:c["chunk_w"] * c["rows"]].reshape(c["rows"], c["chunk_w"])
+        cw = c["chunk_w"]
+        if c["flags"] & 1:                                  # GCN10_TILE_RAW
+            assert len(c["data"]) == c["out_len"]
+            raw = np.frombuffer(c["data"], np.uint8)
+            n_rows = -(-raw.size // cw)
+            t = np.zeros(n_rows * cw, np.uint8)
+            t[:raw.size] = raw
+        else:
+            raw = np.frombuffer(zlib.decompress(c["data"]), np.uint8)
+            assert raw.size >= cw * c["rows"] and cw * c["rows"] <= max_bytes and c["out_len"] == cw * c["rows"]
+            t = raw[:cw * c["rows"]].copy()
+        t = t.reshape(-1, cw)
+        if c["flags"] & 2:                                  # GCN10_TILE_PREDICTOR2
+            t = np.cumsum(t, axis=1, dtype=np.uint64).astype(np.uint8)
+        # the last wanted pixel lies inside what was staged
+        assert (c["src_y"] + c["copy_h"] - 1) * cw + c["src_x"] + c["copy_w"] <= c["out_len"]
         out[c["dst_y"]:c["dst_y"] + c["copy_h"], c["dst_x"]:c["dst_x"] + c["copy_w"]] = \
             t[c["src_y"]:c["src_y"] + c["copy_h"], c["src_x"]:c["src_x"] + c["copy_w"]]
         seen += c["copy_w"] * c["copy_h"]
@@ -326,13 +342,104 @@ def test_read_plan_of_deflate_files_reassembles_every_window(tmp_path, kw):
             r.plan(90, 0, 20, 5)
 
 
-@pytest.mark.parametrize("kw", [dict(compression=5), dict(compression=1), dict(compression=8, predictor=2),
+@pytest.mark.parametrize("kw", [dict(compression=5), dict(compression=5, predictor=2),
                                 dict(compression=32773, rows_per_strip=9)], ids=str)
 def test_read_plan_declines_what_the_gpu_decoder_does_not_take(tmp_path, kw):
     p = str(tmp_path / "t.tif")
     tiffutil.write_tiff(p, _img(8, 40, 60), gt=GT, **kw)
     with host.Raster(p) as r:
         assert r.plan(0, 0, 60, 40) is None
+
+
+@pytest.mark.parametrize("kw", [dict(compression=1, tile=(32, 16)), dict(compression=1, tile=(64, 64)),
+                                dict(compression=1, rows_per_strip=7), dict(compression=1),
+                                dict(compression=8, predictor=2, tile=(32, 32)),
+                                dict(compression=8, predictor=2, rows_per_strip=11),
+                                dict(compression=8, predictor=2, tile=(16, 16), bigtiff=True)], ids=str)
+def test_read_plan_of_raw_and_predictor2_files_reassembles_every_window(tmp_path, kw):
+    """Round 3: uncompressed chunks are planned like DEFLATE ones (staged from the first wanted row / pixel
+    on, untiled on the GPU) and TIFF predictor 2 is a flag of the chunk (summed back on the GPU), for raw
+    and DEFLATE chunks alike.  The plan, carried out here as the GPU side is asked to, equals the host reader."""
+    img = _img(17, 75, 101)
+    p = str(tmp_path / "t.tif")
+    tiffutil.write_tiff(p, img, gt=GT, **kw)
+    with host.Raster(p) as r:
+        for (x, y, w, h) in [(0, 0, 101, 75), (13, 9, 50, 41), (100, 74, 1, 1), (31, 15, 2, 2), (0, 70, 101, 5),
+                             (33, 17, 31, 15)]:
+            plan = r.plan(x, y, w, h)
+            assert plan is not None and plan[1] == w * h
+            want_flags = 1 if kw["compression"] == 1 else (2 if kw.get("predictor") == 2 else 0)
+            assert all(c["flags"] == want_flags for c in plan[0])
+            assert np.array_equal(_assemble(plan, w, h), img[y:y + h, x:x + w]), (x, y, w, h)
+            assert np.array_equal(r.read(x, y, w, h), img[y:y + h, x:x + w])
+
+
+def test_read_plan_leaves_full_width_raw_strips_of_a_wide_raster_to_the_host_reader(tmp_path):
+    """A narrow window of full-width uncompressed strips would stage mostly other blocks' pixels."""
+    img = _img(18, 600, 4000)
+    p = str(tmp_path / "wide.tif")
+    tiffutil.write_tiff(p, img, gt=GT, compression=1, rows_per_strip=600)
+    with host.Raster(p) as r:
+        assert r.plan(10, 0, 100, 600) is None
+        assert r.plan(0, 0, 4000, 600) is not None
+        assert np.array_equal(r.read(10, 0, 100, 600), img[:, 10:110])
+
+
+def test_tiff_writer_extent_writes(tmp_path):
+    """gcn10_tiff_put_extent (round 3: a raster's streams of a strip are one extent of the encoder's arena):
+    one write per call; decoded pixels equal, with buffered writes and -- where the file system allows it --
+    with O_DIRECT (4096-aligned extents)."""
+    import ctypes as C
+    import zlib
+    L = host.lib()
+    L.gcn10_tiff_create.restype = C.c_void_p
+    L.gcn10_tiff_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.c_char_p, C.c_size_t]
+    L.gcn10_tiff_put_extent.restype = C.c_int
+    L.gcn10_tiff_put_extent.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.gcn10_tiff_set_direct.restype = C.c_int
+    L.gcn10_tiff_set_direct.argtypes = [C.c_void_p, C.c_bool]
+    L.gcn10_tiff_finish.restype = C.c_int
+    L.gcn10_tiff_finish.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    W, H = 256 * 5 + 17, 256 * 4 + 3
+    rng = np.random.default_rng(5)
+    img = np.repeat(np.repeat(rng.integers(0, 200, (H // 32 + 1, W // 32 + 1), dtype=np.uint8), 32, axis=0), 32, axis=1)[:H, :W]
+    gt = (C.c_double * 6)(*GT)
+    err = C.create_string_buffer(512)
+    across, down = (W + 255) // 256, (H + 255) // 256
+    for direct in (False, True):
+        p = str(tmp_path / ("w%d.tif" % direct))
+        w = L.gcn10_tiff_create(p.encode(), W, H, gt, None, err, 512)
+        assert w, err.value
+        is_direct = direct and L.gcn10_tiff_set_direct(w, True) == 0       # tmpfs refuses: then buffered
+        for ty in range(down):                              # one extent per tile row, as the pipeline does per strip
+            blobs = []
+            for tx in range(across):
+                tile = np.zeros((256, 256), np.uint8)
+                part = img[ty * 256:(ty + 1) * 256, tx * 256:(tx + 1) * 256]
+                tile[:part.shape[0], :part.shape[1]] = part
+                blobs.append(zlib.compress(tile.tobytes(), 1))
+            rel, at = [], 0
+            for b in blobs:
+                rel.append(at)
+                at = (at + len(b) + 15) & ~15
+            cap = (at + 4095) & ~4095
+            raw = C.create_string_buffer(cap + 4096)
+            base = (C.addressof(raw) + 4095) & ~4095        # 4096-aligned, readable to the next multiple
+            for b, o in zip(blobs, rel):
+                C.memmove(base + o, b, len(b))
+            n = len(blobs)
+            extent = rel[-1] + len(blobs[-1])
+            assert L.gcn10_tiff_put_extent(w, base, extent, n, (C.c_int * n)(*range(across)), (C.c_int * n)(*([ty] * n)),
+                                           (C.c_uint32 * n)(*rel), (C.c_uint32 * n)(*[len(b) for b in blobs])) == 0
+        assert L.gcn10_tiff_finish(w, err, 512) == 0, err.value
+        assert np.array_equal(np.array(Image.open(p)), img), ("direct" if is_direct else "buffered")
+    # a stream that reaches past the extent is refused
+    w = L.gcn10_tiff_create(str(tmp_path / "bad.tif").encode(), 300, 300, gt, None, err, 512)
+    buf = C.create_string_buffer(64)
+    assert L.gcn10_tiff_put_extent(w, C.addressof(buf), 32, 1, (C.c_int * 1)(0), (C.c_int * 1)(0), (C.c_uint32 * 1)(16),
+                                   (C.c_uint32 * 1)(32)) == -1
+    assert L.gcn10_tiff_finish(w, err, 512) != 0
 
 
 def test_read_plan_of_a_vrt_mosaic(tmp_path):

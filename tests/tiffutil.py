@@ -226,3 +226,95 @@ def write_block_shapefile(base, blocks, shape_type=15):
         for i, b in enumerate(blocks):
             f.write(b" " + str(i + 1).rjust(10).encode() + str(b[0]).rjust(10).encode())
         f.write(b"\x1a")
+
+
+def write_cog(path, img, gt=None, tile=(1024, 1024), overviews=2, compression=8, predictor=1, pixel_is_point=False):
+    """A cloud-optimised-GeoTIFF-shaped file, as the ESA WorldCover tiles are
+    (/root/reference/landcover/esa_worldcover_2021.vrt:265-272 names 36000^2 COGs with 1024^2 blocks):
+    the full-resolution IFD first, `overviews` reduced-resolution IFDs (each half the size, NewSubfileType 1)
+    chained behind it, ALL directories in front of the pixel data, and the tile data laid out overviews
+    first (smallest level first), the full-resolution tiles last -- so a reader that takes "the first
+    offsets it finds" or assumes directory order = data order reads an overview.  Classic little-endian TIFF."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    levels = [img]
+    for _ in range(overviews):
+        levels.append(np.ascontiguousarray(levels[-1][::2, ::2]))      # nearest-neighbour overview
+    tw, th = tile
+
+    def enc(c):
+        if predictor == 2 and compression != 1:
+            c = c.astype(np.int16)
+            c[:, 1:] = c[:, 1:] - c[:, :-1]
+            c = (c & 0xFF).astype(np.uint8)
+        raw = c.tobytes()
+        return raw if compression == 1 else zlib.compress(raw, 6)
+
+    blobs = []
+    for lv in levels:
+        H, W = lv.shape
+        bl = []
+        for ty in range(0, H, th):
+            for tx in range(0, W, tw):
+                c = np.zeros((th, tw), np.uint8)
+                part = lv[ty:ty + th, tx:tx + tw]
+                c[:part.shape[0], :part.shape[1]] = part
+                bl.append(enc(c))
+        blobs.append(bl)
+
+    SHORT, LONG, DOUBLE = 3, 4, 12
+    fmt = {SHORT: "H", LONG: "I", DOUBLE: "d"}
+
+    def ifd_bytes(level, ifd_pos, next_ifd, offsets):
+        H, W = levels[level].shape
+        ents = [(256, LONG, [W]), (257, LONG, [H]), (258, SHORT, [8]), (259, SHORT, [compression]),
+                (262, SHORT, [1]), (277, SHORT, [1]), (284, SHORT, [1]),
+                (322, SHORT, [tw]), (323, SHORT, [th]), (324, LONG, offsets), (325, LONG, [len(b) for b in blobs[level]])]
+        if level > 0:
+            ents.append((254, LONG, [1]))                  # NewSubfileType: reduced-resolution image
+        if predictor != 1 and compression != 1:
+            ents.append((317, SHORT, [predictor]))
+        if gt is not None:
+            s = 2 ** level
+            ents.append((33550, DOUBLE, [gt[1] * s, -gt[5] * s, 0.0]))
+            ents.append((33922, DOUBLE, [0.0, 0.0, 0.0, gt[0], gt[3], 0.0]))
+        ents.append((34735, SHORT, [1, 1, 0, 3, 1024, 0, 1, 2, 1025, 0, 1, 2 if pixel_is_point else 1, 2048, 0, 1, 4326]))
+        ents.sort(key=lambda e: e[0])
+        n = len(ents)
+        extra_pos = ifd_pos + 2 + n * 12 + 4
+        ifd, extra = bytearray(struct.pack("<H", n)), bytearray()
+        for tag, typ, vals in ents:
+            payload = struct.pack("<" + fmt[typ] * len(vals), *vals)
+            ifd += struct.pack("<HHI", tag, typ, len(vals))
+            if len(payload) <= 4:
+                ifd += payload + b"\0" * (4 - len(payload))
+            else:
+                ifd += struct.pack("<I", extra_pos + len(extra))
+                extra += payload
+                if len(extra) & 1:
+                    extra += b"\0"
+        ifd += struct.pack("<I", next_ifd)
+        return bytes(ifd + extra)
+
+    # pass 1: sizes of the directories; pass 2: the real offsets
+    sizes = [len(ifd_bytes(l, 0, 0, [0] * len(blobs[l]))) for l in range(len(levels))]
+    ifd_pos, pos = [], 8
+    for sz in sizes:
+        ifd_pos.append(pos)
+        pos += sz + (sz & 1)
+    offsets = [None] * len(levels)
+    body = bytearray()
+    for l in reversed(range(len(levels))):                  # overviews first, full resolution last
+        offs = []
+        for b in blobs[l]:
+            offs.append(pos + len(body))
+            body += b
+            if len(body) & 1:
+                body += b"\0"
+        offsets[l] = offs
+    with open(path, "wb") as f:
+        f.write(b"II" + struct.pack("<HI", 42, ifd_pos[0]))
+        for l in range(len(levels)):
+            d = ifd_bytes(l, ifd_pos[l], ifd_pos[l + 1] if l + 1 < len(levels) else 0, offsets[l])
+            f.write(d + (b"\0" if len(d) & 1 else b""))
+        f.write(body)
+    return levels

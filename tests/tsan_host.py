@@ -3,7 +3,7 @@
 
 Builds bin-like executables from gcn10_amd/csrc/host/*.c with -fsanitize=thread, points GCN10_GPU_LIB
 at the asynchronous host stub (tests/stub_gpu/stub_gpu.c, also instrumented), and drives 3 block
-workers x 8 small blocks through gcn10_run in three sink modes.  Outputs are compared with the oracle
+workers (each with its input thread, round 3) x 8 small blocks through gcn10_run in five input / sink modes.  Outputs are compared with the oracle
 (the stub computes real rasters), and any ThreadSanitizer report fails the run.
 TEST INFRASTRUCTURE ONLY: the stub is never a fallback of the product.
 """
@@ -45,6 +45,9 @@ def main():
     esa = np.where(rng.random(esa.shape) < 0.1, rng.integers(0, 256, esa.shape), esa).astype(np.uint8)
     soil = rng.choice(np.array([0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 255], np.uint8), size=(H // 25 + 2, W // 25 + 2))
     tiffutil.write_tiff(os.path.join(tmp, "esa.tif"), esa, gt=ESA_GT, compression=8, tile=(512, 512))
+    # round 3: uncompressed tiles (staged raw, untiled on the "GPU") and DEFLATE tiles with TIFF predictor 2
+    tiffutil.write_tiff(os.path.join(tmp, "esa_raw.tif"), esa, gt=ESA_GT, compression=1, tile=(256, 128))
+    tiffutil.write_tiff(os.path.join(tmp, "esa_p2.tif"), esa, gt=ESA_GT, compression=8, predictor=2, tile=(512, 256))
     tiffutil.write_tiff(os.path.join(tmp, "soil.tif"), soil, gt=SOIL_GT, compression=5, rows_per_strip=8)
     blocks = []
     for i in range(8):          # 8 blocks of 0.6 x 0.8 degrees = 600 x 800 px, 4 across x 2 down
@@ -57,12 +60,20 @@ def main():
     failed = False
     for mode, extra in (("gpu_deflate=1 gpu_inflate=1", "gpu_deflate=1\ngpu_inflate=1\n"),
                         ("gpu_deflate=0 gpu_inflate=0", "gpu_deflate=0\ngpu_inflate=0\n"),
-                        ("gpu_deflate=1 gpu_inflate=0 lookups=g_ii", "gpu_deflate=1\ngpu_inflate=0\nlookups=g_ii\nconditions=undrained\n")):
+                        ("gpu_deflate=1 gpu_inflate=0 lookups=g_ii", "gpu_deflate=1\ngpu_inflate=0\nlookups=g_ii\nconditions=undrained\n"),
+                        ("gpu_deflate=1 gpu_inflate=1 raw landcover tiles", "gpu_deflate=1\ngpu_inflate=1\nesa=esa_raw.tif\n"),
+                        ("gpu_deflate=1 gpu_inflate=1 predictor-2 landcover, prefetch_blocks=0",
+                         "gpu_deflate=1\ngpu_inflate=1\nprefetch_blocks=0\nesa=esa_p2.tif\n")):
         work = os.path.join(tmp, "run_" + str(len(report)))
         os.makedirs(work)
+        esa_name = "esa.tif"
+        for ln in extra.splitlines():
+            if ln.startswith("esa="):
+                esa_name = ln[4:]
+        extra = "".join(ln + "\n" for ln in extra.splitlines() if not ln.startswith("esa="))
         with open(os.path.join(work, "config.txt"), "w") as f:
             f.write("hysogs_data_path=%s\nesa_data_path=%s\nblocks_shp_path=%s\nlookup_table_path=%s\nlog_dir=%s\n"
-                    "strip_rows=256\nio_threads=4\n%s" % (os.path.join(tmp, "soil.tif"), os.path.join(tmp, "esa.tif"),
+                    "strip_rows=256\nio_threads=4\n%s" % (os.path.join(tmp, "soil.tif"), os.path.join(tmp, esa_name),
                                                           os.path.join(tmp, "blocks.shp"), lookups,
                                                           os.path.join(work, "logs"), extra))
         env = dict(os.environ, GCN10_GPU_LIB=stub, GCN10_OVERSUBSCRIBE="1", GCN10_NO_NUMA_BIND="1",
