@@ -462,6 +462,8 @@ __global__ __launch_bounds__(kBuildThreads) void deflate_codes_kernel(const Tile
         // the fused encoder found this tile equal to another raster's: nothing to build
         book->stream_bytes = 0;
         book->slot = kAliasSlot;
+        job.table[(size_t)tile * 2] = kAliasSlot;
+        job.table[(size_t)tile * 2 + 1] = 0u;
         return;
     }
 
@@ -559,9 +561,10 @@ __global__ __launch_bounds__(kBuildThreads) void deflate_codes_kernel(const Tile
     uint32_t bytes = (bits + 7u) / 8u + 4u;
     if (bytes > (uint32_t)kMaxStream - 64u)
         bytes = (uint32_t)kMaxStream;           // stored fallback
-    // (its place in the arena: deflate_place_kernel, the next launch)
+    // (its place in the arena: deflate_place_kernel, the next launch, from the sizes in the table)
     book->stream_bytes = bytes;
-    book->slot = 0xffffffffu;
+    job.table[(size_t)tile * 2] = 0u;
+    job.table[(size_t)tile * 2 + 1] = bytes;
 }
 
 // ------------------------------------------------------------------------
@@ -674,6 +677,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
         if (lane == 0) {
             book->stream_bytes = 0;
             book->slot = kAliasSlot;
+            job.table[(size_t)tile * 2] = kAliasSlot;
+            job.table[(size_t)tile * 2 + 1] = 0u;
         }
         return;
     }
@@ -977,10 +982,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
         uint32_t bytes = (bits_total + 7u) / 8u + 4u;
         if (bytes > (uint32_t)kMaxStream - 64u)
             bytes = (uint32_t)kMaxStream;       // stored fallback
-        // (its place in the arena: deflate_place_kernel, the next launch)
+        // (its place in the arena: deflate_place_kernel, the next launch, from the sizes in the table)
         book->header_bits = header_bits;
         book->stream_bytes = bytes;
-        book->slot = 0xffffffffu;
+        job.table[(size_t)tile * 2] = 0u;
+        job.table[(size_t)tile * 2 + 1] = bytes;
     }
 }
 
@@ -998,10 +1004,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
 // ------------------------------------------------------------------------
 constexpr int kPlaceThreads = 1024;
 
-__device__ __forceinline__ uint32_t place_need(const TileJob &job, uint32_t i)
+// Pass B left table[i] = { alias mark or 0, stream bytes }: 8 contiguous bytes per stream, so a thread's
+// K consecutive entries are a few cache lines (the first form of this kernel read the sizes out of the
+// 1.1 KB code books: 54 us per strip; this one: a few us).
+__device__ __forceinline__ uint32_t place_need(uint32_t mark, uint32_t bytes)
 {
-    const Book *b = reinterpret_cast<const Book *>(job.books + (size_t)i * kBookBytes);
-    return b->slot == kAliasSlot ? 0u : (b->stream_bytes + (uint32_t)(kSlotAlign - 1)) & ~(uint32_t)(kSlotAlign - 1);
+    return mark == kAliasSlot ? 0u : (bytes + (uint32_t)(kSlotAlign - 1)) & ~(uint32_t)(kSlotAlign - 1);
 }
 
 __global__ __launch_bounds__(kPlaceThreads) void deflate_place_kernel(const TileJob job, uint32_t tiles_per_raster,
@@ -1010,15 +1018,20 @@ __global__ __launch_bounds__(kPlaceThreads) void deflate_place_kernel(const Tile
     __shared__ unsigned long long wave_tot[kPlaceThreads / 64];
     __shared__ unsigned long long P[GCN10_N_RASTERS + 1];       // unaligned prefix at each raster's first stream
     __shared__ unsigned long long seg[GCN10_N_RASTERS + 1];     // where each raster's extent starts
+    constexpr uint32_t kMaxK = 48;                              // entries per thread held in registers (49 152 streams)
     const uint32_t t = threadIdx.x;
     const uint32_t n = job.n_tiles;
     const uint32_t n_rasters = n / tiles_per_raster;
     const uint32_t K = (n + kPlaceThreads - 1) / kPlaceThreads;
     const uint32_t i0 = t * K < n ? t * K : n, i1 = i0 + K < n ? i0 + K : n;
+    const uint2 *tab = reinterpret_cast<const uint2 *>(job.table);
 
     unsigned long long sum = 0;
-    for (uint32_t i = i0; i < i1; i++)
-        sum += place_need(job, i);
+    for (uint32_t i = i0; i < i1; i++) {
+        const uint2 e = tab[i];
+        sum += place_need(e.x, e.y);
+    }
+    (void)kMaxK;
     // exclusive scan over the workgroup
     unsigned long long incl = sum;
 #pragma unroll
@@ -1039,9 +1052,10 @@ __global__ __launch_bounds__(kPlaceThreads) void deflate_place_kernel(const Tile
     {
         unsigned long long running = base;
         for (uint32_t i = i0; i < i1; i++) {
+            const uint2 e = tab[i];
             if (i % tiles_per_raster == 0)
                 P[i / tiles_per_raster] = running;
-            running += place_need(job, i);
+            running += place_need(e.x, e.y);
         }
     }
     if (t == 0)
@@ -1060,23 +1074,26 @@ __global__ __launch_bounds__(kPlaceThreads) void deflate_place_kernel(const Tile
     {
         unsigned long long running = base;
         for (uint32_t i = i0; i < i1; i++) {
-            Book *b = reinterpret_cast<Book *>(job.books + (size_t)i * kBookBytes);
+            const uint2 e = tab[i];
             const uint32_t r = i / tiles_per_raster;
-            const uint32_t need = place_need(job, i);
-            if (b->slot != kAliasSlot) {
+            const uint32_t need = place_need(e.x, e.y);
+            if (e.x != kAliasSlot) {
                 const unsigned long long off = seg[r] + (running - P[r]);
                 const bool fits = off + need <= job.arena_cap;
-                b->slot = fits ? (uint32_t)off : 0xffffffffu;
                 job.table[(size_t)i * 2] = fits ? (uint32_t)off : 0xffffffffu;
-                job.table[(size_t)i * 2 + 1] = fits ? b->stream_bytes : 0u;
+                if (!fits)
+                    job.table[(size_t)i * 2 + 1] = 0u;
             }
             running += need;
         }
     }
-    // the pad between a raster's last stream and the next raster's extent reads as zeros
-    for (uint32_t r = 0; r + 1 < n_rasters; r++) {
+    // the pad between a raster's last stream and the next raster's extent reads as zeros, and so do the
+    // bytes from the last stream's end to the next multiple of the alignment (an O_DIRECT write reads them)
+    for (uint32_t r = 0; r < n_rasters; r++) {
         const unsigned long long from = seg[r] + (P[r + 1] - P[r]);
-        const unsigned long long to = seg[r + 1] < job.arena_cap ? seg[r + 1] : job.arena_cap;
+        unsigned long long to = r + 1 < n_rasters ? seg[r + 1] : (from + seg_align - 1) / seg_align * seg_align;
+        if (to > job.arena_cap)
+            to = job.arena_cap;
         for (unsigned long long o = from + (unsigned long long)t * 16u; o + 16u <= to; o += (unsigned long long)kPlaceThreads * 16u)
             *reinterpret_cast<gcn10::u32x4 *>(job.arena + o) = gcn10::u32x4{ 0u, 0u, 0u, 0u };
     }
@@ -1127,7 +1144,7 @@ __global__ __launch_bounds__(kTile) void deflate_emit_kernel(const TileJob job)
     const uint32_t stream_bytes = book->stream_bytes;
     if ((stream_bytes <= (uint32_t)kSmallStream) != SMALL)
         return;                                     // the other launch emits this tile
-    const uint32_t slot = book->slot;
+    const uint32_t slot = job.table[(size_t)blockIdx.x * 2];       // placed by deflate_place_kernel
     if (slot == 0xffffffffu)
         return;                                     // arena too small: the table says so
     const uint32_t tiles = job.across * job.down;

@@ -424,6 +424,421 @@ __global__ __launch_bounds__(kTile) void fused_stats_kernel(const FusedJob job)
     }
 }
 
+// ------------------------------------------------------------------------
+// pass F-A, segment-parallel form (round 3, the default).  Same outputs as fused_stats_kernel
+// -- the SAME token stream per tile position, bit for bit, and the same statistics of every raster --
+// with four times the lanes: 1024 threads per tile position, ONE LANE PER 64-PIXEL SEGMENT of a
+// tile row, so a lane's two match-candidate masks are one 64-bit word each and its serial walk is at
+// most 64 pixels long (the row-per-lane form walks 256 pixels with four-word masks; its workgroup of
+// four waves, two workgroups per CU by LDS, leaves the SIMDs two waves each -- SQ counters of round
+// 2: a wave issues 42 % of the time and waits 50 %).  With 16 waves per workgroup the same 66.5 KB of
+// LDS feed eight waves per SIMD.
+// The greedy parse of a row is a chain (a match decides where the next token starts), and matches
+// cross segment boundaries.  It is kept exact in two steps.  (1) Every lane publishes how many
+// leading pixels of its segment continue a run from the segment before ("leads", for both
+// distances), so a lane can tell the full length of a match that leaves its segment, and every lane
+// parses its segment SPECULATIVELY from pixel 0.  (2) Segment by segment (three workgroup barriers),
+// a lane reads where the last match of the segment before it really ended -- its entry offset --
+// and, if that is not 0, re-parses from there only until it stands on a token start of its
+// speculative parse: greedy parsing depends on the position alone, so from that pixel on the two
+// parses are the same and the speculative tokens are kept (typically after one or two tokens).
+// Tokens are written in raster order (row-major, segment by segment), so pass F-C, pass B and the
+// host see exactly what the row form produced.
+// ------------------------------------------------------------------------
+constexpr int kSegs = 4;
+constexpr int kSegPx = kTile / kSegs;               // 64
+constexpr int kFA2Threads = kTile * kSegs;          // 1024
+
+struct SharedFA2 {
+    uint8_t tile[kTile * kRowStride];
+    uint32_t soil_row[kTile];
+    union {
+        uint8_t class_of[gcn10::kClassCodes * 256];     // while the tile is built
+        struct {
+            uint32_t lit_hist[288];
+            uint32_t dist_hist[2];
+            uint32_t n_c[256], w_c[256];
+            union {
+                uint32_t H[kGroup][256];                    // after the tokens are out
+                struct {
+                    uint32_t seg_at[kFA2Threads];           // tokens of (row, seg) in raster order, then their exclusive prefix
+                    uint32_t wave_tot[kFA2Threads / 64];
+                    uint8_t lead_n[kTile][kSegs];           // leading pixels of (row, seg) that continue a distance-1 run
+                    uint8_t lead_f[kTile][kSegs];           // ... that equal the row above (0 .. 64)
+                    uint16_t exit_at[kTile][kSegs];         // pixels by which the last match of (row, seg) overhangs it
+                };
+            };
+            uint32_t s1[GCN10_N_RASTERS], s2[GCN10_N_RASTERS];
+            uint32_t sig[GCN10_N_RASTERS], cand[GCN10_N_RASTERS], differ;
+            uint32_t alias[GCN10_N_RASTERS];
+        } a;
+    };
+};
+
+__device__ __forceinline__ int run64(unsigned long long m, int p)
+{
+    // consecutive set bits of m starting at bit p (0 <= p < 64), counted to the word's end
+    const unsigned long long inv = ~(m >> p);       // the bits shifted in from above are zeros: inv != 0 unless p == 0 and m is all ones
+    return inv ? __builtin_ctzll(inv) : 64;
+}
+
+__global__ __launch_bounds__(kFA2Threads, 8) void fused_stats_seg_kernel(const FusedJob job)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    SharedFA2 &sh = *reinterpret_cast<SharedFA2 *>(smem);
+    typedef uint32_t u32_u __attribute__((aligned(1)));
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int seg = __builtin_amdgcn_readfirstlane(t >> 8);     // a wave is 64 consecutive rows of one segment
+    const int row = t & 255;
+    const uint32_t tiles = job.t.across * job.t.down;
+    const uint32_t tix = blockIdx.x;
+    const uint32_t ty = tix / job.t.across, tx = tix - ty * job.t.across;
+    const uint8_t *class_val = job.class_of + gcn10::kClassCodes * 256;
+
+    for (int i = t; i < gcn10::kClassCodes * 256 / 4; i += kFA2Threads)
+        reinterpret_cast<uint32_t *>(sh.class_of)[i] = reinterpret_cast<const uint32_t *>(job.class_of)[i];
+    if (t < kTile) {
+        const uint32_t y = ty * kTile + (uint32_t)t;
+        uint32_t srow = y < job.t.rows ? (uint32_t)job.cj[y] : 0u;
+        sh.soil_row[t] = srow < job.hx_rows ? srow : job.hx_rows - 1u;
+    }
+    __syncthreads();
+    // class tile: thread = 4 columns x 16 rows (rows (t >> 6) + 16 i)
+    {
+        const uint32_t x = tx * kTile + (uint32_t)lane * 4u;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(sh.tile) + lane;
+        const int r0 = t >> 6;
+        if ((tx + 1) * kTile <= job.t.W && (ty + 1) * kTile <= job.t.rows) {
+            const uint8_t *pe = job.esa + ((size_t)ty * kTile + (uint32_t)r0) * job.t.W + x;
+            const uint8_t *ph = job.hx + x;
+            uint32_t e4[16], c4[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                e4[i] = *reinterpret_cast<const u32_u *>(pe + (size_t)i * 16 * job.t.W);
+                c4[i] = *reinterpret_cast<const u32_u *>(ph + (size_t)sh.soil_row[r0 + 16 * i] * job.hx_stride);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                uint32_t out = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) {
+                    const uint32_t lc = (e4[i] >> (8 * q)) & 0xffu;
+                    const uint32_t cc = compact_code((c4[i] >> (8 * q)) & 0xffu);
+                    out |= (uint32_t)sh.class_of[cc * 256u + lc] << (8 * q);
+                }
+                dst[(r0 + 16 * i) * (kRowStride / 4)] = out;
+            }
+        }
+        else {
+#pragma unroll 4
+            for (int i = 0; i < 16; i++) {
+                const int r = r0 + 16 * i;
+                dst[r * (kRowStride / 4)] = class_pixels4(job, x, ty * kTile + (uint32_t)r, sh.class_of);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < 288; i += kFA2Threads)
+        sh.a.lit_hist[i] = 0;
+    if (t < 2)
+        sh.a.dist_hist[t] = 0;
+    if (t < 256) {
+        sh.a.n_c[t] = 0;
+        sh.a.w_c[t] = 0;
+    }
+    if (t < GCN10_N_RASTERS) {
+        sh.a.s1[t] = 0;
+        sh.a.s2[t] = 0;
+    }
+
+    // the two candidate masks of this lane's 64 pixels
+    unsigned long long near_ = 0, far_ = 0;
+    const uint8_t *rowp = sh.tile + row * kRowStride;
+    {
+        const uint32_t *r32 = reinterpret_cast<const uint32_t *>(rowp) + seg * 16;
+        const uint32_t *above = r32 - kRowStride / 4;
+        uint32_t prev = seg > 0 ? r32[-1] : (row > 0 ? above[63] : 0u);      // (seg 0: the stream's previous byte is the row above's last)
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t r = r32[j];
+            const uint32_t shifted = (r << 8) | (prev >> 24);
+            near_ |= (unsigned long long)zero_bytes(r ^ shifted) << (4 * j);
+            if (row > 0)
+                far_ |= (unsigned long long)zero_bytes(r ^ above[j]) << (4 * j);
+            prev = r;
+        }
+        if (row == 0 && seg == 0)
+            near_ &= ~1ull;             // the tile's first byte has no predecessor
+    }
+    sh.a.lead_n[row][seg] = (uint8_t)(~near_ ? __builtin_ctzll(~near_) : kSegPx);
+    sh.a.lead_f[row][seg] = (uint8_t)(~far_ ? __builtin_ctzll(~far_) : kSegPx);
+    __syncthreads();
+
+    // pixels and Adler weights per class, run by run (a run that crosses into the next segment is
+    // counted in two pieces: both sums are additive)
+    {
+        unsigned long long brk = ~near_ | 1ull;
+        const uint32_t i0 = (uint32_t)row * kTile + (uint32_t)seg * kSegPx;    // index of the segment's first byte in the tile
+        while (brk) {
+            const int x0 = __builtin_ctzll(brk);
+            brk &= brk - 1ull;
+            const int x1 = brk ? __builtin_ctzll(brk) : kSegPx;
+            const uint32_t n = (uint32_t)(x1 - x0);
+            const uint32_t c = rowp[seg * kSegPx + x0];
+            // sum of (65536 - i) over i = i0 + x0 .. i0 + x1 - 1
+            atomicAdd(&sh.a.n_c[c], n);
+            atomicAdd(&sh.a.w_c[c], n * ((uint32_t)kTileBytes - i0) - ((n * (uint32_t)(x0 + x1 - 1)) >> 1));
+        }
+    }
+
+    // length of the run of `far ? far_ : near_` that starts at pixel p of this segment, followed into the
+    // segments behind it
+    auto ext_run = [&](bool far, int p) -> int {
+        int r = run64(far ? far_ : near_, p);
+        if (p + r == kSegPx)
+            for (int k = seg + 1; k < kSegs; k++) {
+                const int l = far ? sh.a.lead_f[row][k] : sh.a.lead_n[row][k];
+                r += l;
+                if (l < kSegPx)
+                    break;
+            }
+        return r;
+    };
+    // where a match can start: a run of >= 3 at either distance (the last two pixels look into the next segment)
+    unsigned long long cand;
+    {
+        const uint32_t ln = seg + 1 < kSegs ? sh.a.lead_n[row][seg + 1] : 0u, lf = seg + 1 < kSegs ? sh.a.lead_f[row][seg + 1] : 0u;
+        const unsigned long long n2 = ln >= 2u ? 3ull : ln, f2 = lf >= 2u ? 3ull : lf;
+        cand = (near_ & ((near_ >> 1) | (n2 & 1ull) << 63) & ((near_ >> 2) | n2 << 62)) |
+               (far_ & ((far_ >> 1) | (f2 & 1ull) << 63) & ((far_ >> 2) | f2 << 62));
+    }
+    auto span = [](int from, int to) -> unsigned long long {       // bits from .. min(to, 64) - 1
+        const unsigned long long hi = to >= kSegPx ? ~0ull : (1ull << to) - 1ull;
+        return hi & (~0ull << from);
+    };
+    // (1) speculative parse from pixel 0
+    unsigned long long starts = 0, fars = 0, covered = 0;
+    uint32_t exit_over = 0;
+    {
+        int pos = 0;
+        while (pos < kSegPx) {
+            const unsigned long long rest = cand >> pos;
+            if (!rest)
+                break;
+            const int p = pos + __builtin_ctzll(rest);
+            const int l1 = ext_run(false, p), l256 = ext_run(true, p);
+            const bool far = l256 > l1;                 // tie: distance 1 (no extra bits)
+            const int len = far ? l256 : l1;            // >= 3: bit p of cand is set
+            starts |= 1ull << p;
+            fars |= far ? 1ull << p : 0ull;
+            covered |= span(p, p + len);
+            pos = p + len;
+        }
+        exit_over = pos > kSegPx ? (uint32_t)(pos - kSegPx) : 0u;
+    }
+    // (2) the real entry offset, segment by segment
+    if (seg == 0)
+        sh.a.exit_at[row][0] = (uint16_t)exit_over;
+    for (int sgm = 1; sgm < kSegs; sgm++) {
+        __syncthreads();
+        if (seg != sgm)
+            continue;
+        const uint32_t over = sh.a.exit_at[row][sgm - 1];
+        if (over >= (uint32_t)kSegPx) {
+            // the whole segment lies inside a match that started before it
+            starts = fars = 0;
+            covered = ~0ull;
+            exit_over = over - (uint32_t)kSegPx;
+        }
+        else if (over > 0) {
+            const unsigned long long s_tok = ~covered | starts;    // token starts of the speculative parse
+            unsigned long long r_starts = 0, r_fars = 0, r_cov = (1ull << over) - 1ull;
+            int pos = (int)over;
+            for (;;) {
+                if (pos >= kSegPx) {                    // no meeting point: the re-parse is the parse
+                    starts = r_starts;
+                    fars = r_fars;
+                    covered = r_cov;
+                    exit_over = (uint32_t)(pos - kSegPx);
+                    break;
+                }
+                const unsigned long long tq = s_tok >> pos, rest = cand >> pos;
+                const int q = tq ? pos + __builtin_ctzll(tq) : kSegPx, p = rest ? pos + __builtin_ctzll(rest) : kSegPx;
+                if (q <= p) {
+                    // pixels pos .. q-1 are literals; at q both parses stand on a token start: the same from there on
+                    const unsigned long long hi = q < kSegPx ? ~0ull << q : 0ull;
+                    starts = r_starts | (starts & hi);
+                    fars = r_fars | (fars & hi);
+                    covered = r_cov | (covered & hi);
+                    if (q >= kSegPx)
+                        exit_over = 0;
+                    break;
+                }
+                const int l1 = ext_run(false, p), l256 = ext_run(true, p);
+                const bool far = l256 > l1;
+                const int len = far ? l256 : l1;
+                r_starts |= 1ull << p;
+                r_fars |= far ? 1ull << p : 0ull;
+                r_cov |= span(p, p + len);
+                pos = p + len;
+            }
+        }
+        if (sgm + 1 < kSegs)
+            sh.a.exit_at[row][sgm] = (uint16_t)exit_over;
+    }
+    // statistics of the final parse
+    const unsigned long long lits = ~covered;
+    const uint32_t my_tokens = (uint32_t)__popcll(lits) + (uint32_t)__popcll(starts);
+    for (unsigned long long m = starts; m; m &= m - 1ull) {
+        const int p = __builtin_ctzll(m);
+        const bool far = ((fars >> p) & 1ull) != 0;
+        atomicAdd(&sh.a.lit_hist[257 + length_code(ext_run(far, p))], 1u);
+        atomicAdd(&sh.a.dist_hist[far ? 1 : 0], 1u);
+    }
+    if (!(job.diag & 8u))
+        for (unsigned long long m = lits; m; m &= m - 1ull)
+            atomicAdd(&sh.a.lit_hist[rowp[seg * kSegPx + __builtin_ctzll(m)]], 1u);
+    __syncthreads();            // (the leads are read above; seg_at below shares their memory with nothing, but the scan needs all counts)
+
+    // raster order = (row, seg): an exclusive prefix over the 1024 counts says where each segment's tokens go
+    sh.a.seg_at[row * kSegs + seg] = my_tokens;
+    __syncthreads();
+    {
+        const uint32_t mine = sh.a.seg_at[t];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, 64);
+            if (lane >= off)
+                incl += up;
+        }
+        if (lane == 63)
+            sh.a.wave_tot[t >> 6] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (int w = 0; w < (t >> 6); w++)
+            before += sh.a.wave_tot[w];
+        sh.a.seg_at[t] = before + incl - mine;
+        __syncthreads();
+    }
+    {
+        uint32_t at = sh.a.seg_at[row * kSegs + seg];
+        uint16_t *out = job.tok + (size_t)tix * kTokStride;
+        if (!(job.diag & 16u)) {
+            for (unsigned long long m = lits | starts; m; m &= m - 1ull) {
+                const int p = __builtin_ctzll(m);
+                if ((lits >> p) & 1ull) {
+                    out[at++] = (uint16_t)rowp[seg * kSegPx + p];
+                }
+                else {
+                    const bool far = ((fars >> p) & 1ull) != 0;
+                    const int len = ext_run(far, p);
+                    const int lc = length_code(len);
+                    out[at++] = (uint16_t)(kTokMatch | (uint32_t)lc | (uint32_t)(len - (lc == 28 ? 258 : kLenBase[lc])) << 5 |
+                                           (far ? 1u : 0u) << 10);
+                }
+            }
+        }
+        else {
+            at += my_tokens;
+        }
+        if (t == kFA2Threads - 1) {
+            out[at] = (uint16_t)kTokEnd;
+            job.n_tok[tix] = at + 1u;
+        }
+    }
+    __syncthreads();
+
+    // From here on: per class (thread = class), exactly as the row form.  Threads 256.. only keep the barriers.
+    const bool cls = t < 256;
+    const uint32_t lits_c = cls ? sh.a.lit_hist[t] : 0u;
+    {
+        const uint32_t n = cls ? sh.a.n_c[t] : 0u;
+        const uint32_t w = cls ? sh.a.w_c[t] % 65521u : 0u;
+        const bool present = n != 0;
+        if (t < GCN10_N_RASTERS)
+            sh.a.sig[t] = 0;
+        if (t == 0)
+            sh.a.differ = 0;
+        __syncthreads();
+        if (cls)
+            for (uint32_t j = 0; j < job.n_sel; j++) {
+                const uint32_t v = class_val[job.sel[j] * 256 + t];
+                uint32_t h = present ? (((uint32_t)t * 0x9E3779B1u + v * 0x85EBCA6Bu + 0x27D4EB2Fu) * 0x165667B1u) : 0u;
+                h ^= h >> 15;
+                const uint32_t p1 = wave_sum64(n * v), p2 = wave_sum64(w * v), p3 = wave_sum64(h);
+                if (lane == 0) {
+                    atomicAdd(&sh.a.s1[j], p1);
+                    atomicAdd(&sh.a.s2[j], p2);
+                    atomicAdd(&sh.a.sig[j], p3);
+                }
+            }
+    }
+    {
+        const bool present = cls && sh.a.n_c[t] != 0;
+        __syncthreads();
+        if ((uint32_t)t < job.n_sel) {
+            uint32_t cand = 0xffu;
+            for (uint32_t q = 0; q < (uint32_t)t; q++)
+                if (cand == 0xffu && sh.a.sig[q] == sh.a.sig[t])
+                    cand = q;
+            sh.a.cand[t] = cand;
+        }
+        __syncthreads();
+        {
+            uint32_t mine = 0;
+            if (present)
+                for (uint32_t j = 1; j < job.n_sel; j++) {
+                    const uint32_t q = sh.a.cand[j];
+                    if (q != 0xffu && class_val[job.sel[j] * 256 + t] != class_val[job.sel[q] * 256 + t])
+                        mine |= 1u << j;
+                }
+            if (mine)
+                atomicOr(&sh.a.differ, mine);
+        }
+        __syncthreads();
+        if ((uint32_t)t < job.n_sel) {
+            const uint32_t q = sh.a.cand[t];
+            sh.a.alias[t] = (q != 0xffu && !((sh.a.differ >> t) & 1u)) ? (kAliasFlag | q) : 0u;
+        }
+    }
+    // per raster: literal counts by VALUE, kGroup rasters per round; the 1024 threads write the statistics out
+    for (uint32_t j0 = 0; j0 < job.n_sel; j0 += kGroup) {
+        const uint32_t nj = job.n_sel - j0 < (uint32_t)kGroup ? job.n_sel - j0 : (uint32_t)kGroup;
+        if (cls)
+            for (uint32_t k = 0; k < nj; k++)
+                sh.a.H[k][t] = 0;
+        __syncthreads();
+        if (lits_c)
+            for (uint32_t k = 0; k < nj; k++)
+                atomicAdd(&sh.a.H[k][class_val[job.sel[j0 + k] * 256 + t]], lits_c);
+        __syncthreads();
+        for (uint32_t idx = (uint32_t)t; idx < nj * (uint32_t)kHistWords; idx += kFA2Threads) {
+            const uint32_t k = idx / (uint32_t)kHistWords;
+            const int i = (int)(idx - k * (uint32_t)kHistWords);
+            const uint32_t j = j0 + k;
+            uint32_t v;
+            if (i < 256)
+                v = sh.a.H[k][i];
+            else if (i == 256)
+                v = 1u;                             // end of block
+            else if (i < 288)
+                v = sh.a.lit_hist[i];               // match length symbols: the same for every raster
+            else if (i < 290)
+                v = sh.a.dist_hist[i - 288];
+            else if (i == 290)
+                v = (((65536u % 65521u + sh.a.s2[j] % 65521u) % 65521u) << 16) | ((1u + sh.a.s1[j]) % 65521u);
+            else if (i == 291)
+                v = sh.a.alias[j];
+            else
+                v = 0u;
+            job.t.hist[((size_t)j * tiles + tix) * kHistWords + i] = v;
+        }
+        __syncthreads();
+    }
+}
+
 // Inclusive prefix sum over the 64 lanes with DPP adds (no LDS traffic): three shifted adds of
 // the input give sums over 4 lanes, row_shr:4 / row_shr:8 complete the rows of 16, row_bcast:15
 // and row_bcast:31 carry the row totals on.
@@ -481,7 +896,7 @@ __global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
         int mine = 0, st = 0;
         if ((uint32_t)t < nj) {
             const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)(j0 + t) * tiles + tix) * kBookBytes);
-            mine = b->slot < kAliasSlot;             // neither "arena too small" nor an alias
+            mine = job.t.table[((size_t)(j0 + t) * tiles + tix) * 2] < kAliasSlot;      // neither "arena too small" nor an alias
             st = mine && b->stream_bytes == (uint32_t)kMaxStream;
             // an alias's table entry is its original's (written by pass B, a launch ago)
             const uint32_t al = job.t.hist[((size_t)(j0 + t) * tiles + tix) * kHistWords + 291];
@@ -517,7 +932,7 @@ __global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
             continue;
         const uint32_t j = j0 + k;
         const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)j * tiles + tix) * kBookBytes);
-        words[k] = reinterpret_cast<uint32_t *>(job.t.arena + b->slot);
+        words[k] = reinterpret_cast<uint32_t *>(job.t.arena + job.t.table[((size_t)j * tiles + tix) * 2]);
         base[k] = b->header_bits;
         dcode0[k] = b->dist_code[0];
         dlen0[k] = b->dist_len[0];
@@ -620,7 +1035,7 @@ __global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
         const uint32_t j = j0 + (uint32_t)t;
         const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)j * tiles + tix) * kBookBytes);
         const uint32_t adler = job.t.hist[((size_t)j * tiles + tix) * kHistWords + 290];
-        uint32_t *w = reinterpret_cast<uint32_t *>(job.t.arena + b->slot);
+        uint32_t *w = reinterpret_cast<uint32_t *>(job.t.arena + job.t.table[((size_t)j * tiles + tix) * 2]);
         const uint32_t at = b->stream_bytes - 4u;
 #pragma unroll
         for (uint32_t i = 0; i < 4; i++) {
@@ -641,8 +1056,7 @@ __global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
         if (!((stored_mask >> k) & 1u))
             continue;
         const uint32_t j = j0 + k;
-        const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)j * tiles + tix) * kBookBytes);
-        uint8_t *o = job.t.arena + b->slot;
+        uint8_t *o = job.t.arena + job.t.table[((size_t)j * tiles + tix) * 2];
         const uint32_t adler = job.t.hist[((size_t)j * tiles + tix) * kHistWords + 290];
         if (t == 0) {
             o[0] = 0x78;
@@ -749,16 +1163,22 @@ int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W,
     job.n_tok = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(ctx->deflate_ws) + stats_bytes + tok_bytes);
 
     static_assert(sizeof(SharedFA) <= 80 * 1024, "two fused statistics workgroups per CU");
+    static_assert(sizeof(SharedFA2) <= 80 * 1024, "two segment-parallel statistics workgroups (32 waves) per CU");
     static_assert(sizeof(SharedFC) <= 20 * 1024, "eight fused emit workgroups per CU");
     if (!ctx->fused_ready) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_stats_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SharedFA)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_stats_seg_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SharedFA2)));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_emit_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SharedFC)));
         ctx->fused_ready = true;
     }
     hipStream_t s = as_stream(ctx, stream);
-    hipLaunchKernelGGL(fused_stats_kernel, dim3(positions), dim3(kTile), sizeof(SharedFA), s, job);
+    if (ctx->fused_parse == 0)
+        hipLaunchKernelGGL(fused_stats_kernel, dim3(positions), dim3(kTile), sizeof(SharedFA), s, job);
+    else
+        hipLaunchKernelGGL(fused_stats_seg_kernel, dim3(positions), dim3(kFA2Threads), sizeof(SharedFA2), s, job);
     rc = gcn10::deflate_launch_codes(ctx, job.t, (uint32_t)nblocks, s);
     if (rc)
         return rc;

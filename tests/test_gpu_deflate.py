@@ -190,6 +190,54 @@ def test_fused_encoder_full_block_width(engine, tables, pattern):
     _fused_case(engine, tables, 512, 36000, seed=21, nasty=False, coherent=False, esa_override=esa)
 
 
+@pytest.mark.parametrize("texture", ["natural", "patches", "iid", "runs", "rows", "constant", "stripes63"])
+def test_segment_parallel_parse_is_the_row_parse_bit_for_bit(engine, tables, texture):
+    """Round 3: pass F-A with one lane per 64-pixel segment (speculative parse + entry offsets, option
+    fused_parse=1, the default) writes the same token stream as one lane per row (fused_parse=0): arena
+    bytes, stream table and bytes used are identical, for textures whose matches end inside, at and far
+    beyond segment boundaries (whole-row matches, runs of 63 / 64 / 65 pixels, vertical repeats)."""
+    import bench
+    from gcn10_amd import host
+    H, W = 512, 2 * 256 + 100
+    rng = np.random.default_rng(31)
+    classes = np.array([10, 20, 30, 40, 50, 60, 70, 80, 90, 95, 100], np.uint8)
+    if texture in ("natural", "patches", "iid"):
+        esa = np.ascontiguousarray(bench.synth_block(4, 1024, texture)[0][:H, :W])
+    elif texture == "runs":          # runs of 1 .. 200 pixels: matches cross one, two and three boundaries
+        runs = rng.integers(1, 200, size=H * W // 20)
+        esa = np.repeat(classes[rng.integers(0, len(classes), len(runs))], runs)[:H * W].reshape(H, W).copy()
+    elif texture == "rows":          # every row a copy of the one above, except where it is not
+        esa = np.tile(classes[rng.integers(0, len(classes), W)], (H, 1))
+        esa[rng.integers(0, H, 40), rng.integers(0, W, 40)] = 0
+        esa = np.ascontiguousarray(esa)
+    elif texture == "constant":
+        esa = np.full((H, W), 80, np.uint8)
+        esa[100, 300] = 10
+    else:                            # stripes of 63, 64 and 65 pixels: matches that end just before, at and after a boundary
+        row = np.concatenate([np.full(n, classes[k % len(classes)], np.uint8) for k, n in enumerate([63, 64, 65, 1, 2, 64, 127, 128, 98])])
+        esa = np.ascontiguousarray(np.tile(row[:W], (H, 1)))
+        esa[::7, ::61] = 30
+    coarse = rng.choice(np.array([0, 1, 2, 3, 4, 11, 12, 13, 14, 255], np.uint8), size=(H // 25 + 2, W // 25 + 2))
+    gt = [0.0, 3.0 / W, 0.0, 3.0, 0.0, -3.0 / W]
+    sgt = [-0.01, 3.02 / coarse.shape[1], 0.0, 3.01, 0.0, -3.02 / coarse.shape[0]]
+    ci, cj = host.build_index_maps(gt, sgt, W, H, coarse.shape[1], coarse.shape[0])
+    engine.set_tables(tables)
+    bufs = [engine.upload(a) for a in (esa, coarse, ci, cj)]
+    engine.prepare_tile(bufs[1].ptr, coarse.shape[1], coarse.shape[0], bufs[2].ptr, W)
+    out = {}
+    try:
+        for parse in (0, 1):
+            engine.set_option("fused_parse", parse)
+            out[parse] = engine.deflate_fused(bufs[0].ptr, W, H, bufs[3].ptr)
+    finally:
+        engine.set_option("defaults", 0)
+        for b in bufs:
+            b.close()
+    assert out[0][2] == out[1][2], "bytes used differ: %d vs %d" % (out[0][2], out[1][2])
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][0], out[1][0])
+
+
 def test_fused_encoder_shares_streams_where_drained_equals_undrained(engine, tables):
     """No dual soil class (11..14) under a tile: the drained and the undrained raster of a table
     are the same bytes there, and the fused encoder emits them once -- both table entries point
