@@ -1089,6 +1089,363 @@ __global__ __launch_bounds__(kTile) void fused_emit_kernel(const FusedJob job)
     }
 }
 
+// ------------------------------------------------------------------------
+// pass F-C, wave-independent form (round 3, the default).  Same streams as fused_emit_kernel, bit for
+// bit.  That kernel walks the token stream 256 tokens per trip with all four waves in lock step, one
+// token per lane, and ORs every token's bits into LDS staging words with three 32-bit atomics per
+// stream.  Timing switches (profiles/r03) put its time in two places: LDS atomics whose lanes hit the
+// same word (a token is ~8 bits: eight neighbouring lanes per 64-bit word, executed one after the
+// other) and the write-out of ~20 staged words per stream and trip behind them -- with the next trip's
+// token load queued behind those stores (vmcnt is one in-order queue).  Here
+//   * every wave owns one contiguous QUARTER of the position's tokens: phase 1 adds up the bits its
+//     quarter takes in each of the group's streams (no packing), ONE workgroup barrier, and the sums
+//     before it say where the wave's bits begin in every stream; nothing is shared after that;
+//   * a lane takes FOUR consecutive tokens and packs their codes into a register chunk (<= 164 bits)
+//     before anything touches LDS: a wave's trip is 256 tokens, a lane's chunk is ~40 bits, so at most
+//     two lanes meet in a 64-bit staging word and there are a quarter of the atomics;
+//   * the group's six codes of a class are ONE 16-byte LDS row (20 bits per stream: code | length << 15);
+//   * the next trip's tokens are loaded before this trip's words are stored.
+// ------------------------------------------------------------------------
+constexpr int kLaneToks = 4;                        // consecutive tokens per lane and trip
+constexpr int kTripToks = 64 * kLaneToks;           // 256 tokens per wave and trip
+constexpr int kStage64 = (63 + kTripToks * 41 + 63) / 64 + 2;      // a trip's bits starting anywhere in the first word: 166 words
+
+struct SharedFC2 {
+    union {
+        struct {
+            unsigned long long cl[288][2];                          // 20 bits per stream: code | length << 15; streams 0-2, 3-5
+            unsigned long long stage[4][kStage64];                  // per wave: the bits of one trip of one stream
+        } c;
+        uint8_t class_of[gcn10::kClassCodes * 256];                 // stored fallback only, after the streams
+    };
+    uint32_t chunk_bits[kGroup][4];         // bits of each wave's quarter, per stream
+    uint32_t masks[2];
+};
+
+// what a 16-bit token says: symbol, extra bits of a length, which distance
+struct TokFields {
+    uint32_t sym, ne, ev;
+    bool is_match, far;
+};
+
+__device__ __forceinline__ TokFields tok_fields(uint32_t tk)
+{
+    TokFields f;
+    f.is_match = (tk & kTokMatch) != 0;
+    const uint32_t lc = tk & 31u;
+    f.sym = f.is_match ? 257u + lc : (tk & kTokEnd) ? 256u : (tk & 255u);
+    f.ne = !f.is_match || lc < 8u || lc == 28u ? 0u : (lc - 4u) >> 2;
+    f.ev = f.is_match ? (tk >> 5) & 31u : 0u;
+    f.far = ((tk >> 10) & 1u) != 0;
+    return f;
+}
+
+// code | length << 15 of stream k (0..5) from the two halves of a cl row
+__device__ __forceinline__ uint32_t cl_field(unsigned long long h0, unsigned long long h1, int k)
+{
+    return (uint32_t)((k < 3 ? h0 : h1) >> (20 * (k % 3))) & 0xfffffu;
+}
+
+__global__ __launch_bounds__(kTile, 6) void fused_emit_wave_kernel(const FusedJob job)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    SharedFC2 &sh = *reinterpret_cast<SharedFC2 *>(smem);
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint32_t tiles = job.t.across * job.t.down;
+    const uint32_t tix = blockIdx.x;
+    const uint32_t ty = tix / job.t.across, tx = tix - ty * job.t.across;
+    const uint32_t j0 = blockIdx.y * kGroup;
+    const uint32_t nj = job.n_sel - j0 < (uint32_t)kGroup ? job.n_sel - j0 : (uint32_t)kGroup;
+    const uint8_t *class_val = job.class_of + gcn10::kClassCodes * 256;
+
+    // which rasters of the group have a slot, and which of those are stored
+    uint32_t live, stored_mask;
+    {
+        int mine = 0, st = 0;
+        if ((uint32_t)t < nj) {
+            const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)(j0 + t) * tiles + tix) * kBookBytes);
+            mine = job.t.table[((size_t)(j0 + t) * tiles + tix) * 2] < kAliasSlot;      // neither "arena too small" nor an alias
+            st = mine && b->stream_bytes == (uint32_t)kMaxStream;
+            // an alias's table entry is its original's (placed by pass B', a launch ago)
+            const uint32_t al = job.t.hist[((size_t)(j0 + t) * tiles + tix) * kHistWords + 291];
+            if (al & kAliasFlag) {
+                const size_t from = ((size_t)(al & 0xffu) * tiles + tix) * 2, to = ((size_t)(j0 + t) * tiles + tix) * 2;
+                job.t.table[to] = job.t.table[from];
+                job.t.table[to + 1] = job.t.table[from + 1];
+            }
+        }
+        live = (uint32_t)__ballot(mine);
+        stored_mask = (uint32_t)__ballot(st);
+        if (t == 0) {
+            sh.masks[0] = live;
+            sh.masks[1] = stored_mask;
+        }
+        __syncthreads();
+        live = sh.masks[0];
+        stored_mask = sh.masks[1];
+        if (live == 0)
+            return;
+    }
+    const uint32_t coded = __builtin_amdgcn_readfirstlane(live & ~stored_mask);     // rasters that get a Huffman stream
+
+    // per stream: where it lies, where its tokens begin, its two distance codes (wave-uniform: scalar registers)
+    unsigned long long *words[kGroup];
+    uint32_t base[kGroup], dcode0[kGroup], dlen0[kGroup], dcode1[kGroup], dlen1[kGroup];
+    for (int i = t; i < 288 * 2; i += kTile)
+        (&sh.c.cl[0][0])[i] = 0ull;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kGroup; k++) {
+        words[k] = nullptr;
+        base[k] = dcode0[k] = dlen0[k] = dcode1[k] = dlen1[k] = 0;
+        if (!((coded >> k) & 1u))
+            continue;
+        const uint32_t j = j0 + k;
+        const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)j * tiles + tix) * kBookBytes);
+        uint32_t *w32 = reinterpret_cast<uint32_t *>(job.t.arena + job.t.table[((size_t)j * tiles + tix) * 2]);
+        words[k] = reinterpret_cast<unsigned long long *>(w32);
+        base[k] = __builtin_amdgcn_readfirstlane(b->header_bits);
+        dcode0[k] = __builtin_amdgcn_readfirstlane((uint32_t)b->dist_code[0]);
+        dlen0[k] = __builtin_amdgcn_readfirstlane((uint32_t)b->dist_len[0]);
+        dcode1[k] = __builtin_amdgcn_readfirstlane((uint32_t)b->dist_code[1] | 63u << b->dist_len[1]);     // + 6 extra bits: 256 - 193
+        dlen1[k] = __builtin_amdgcn_readfirstlane((uint32_t)b->dist_len[1] + 6u);
+        // the zeroed slot with its block header, up to the slot's 16-byte end (the host writes a raster's
+        // streams of a strip as one extent: the bytes between two streams are zeros)
+        const uint32_t n_words = (b->stream_bytes + 15u) / 16u * 4u;
+        for (uint32_t i = t; i < n_words; i += kTile)
+            w32[i] = i < 64u ? b->header[i] : 0u;
+        // (k-th 20-bit field of its half: every (i, k) is touched by one thread, the halves were zeroed above)
+        for (int i = t; i < 288; i += kTile) {
+            const uint32_t sym = i < 256 ? class_val[job.sel[j] * 256 + i] : (uint32_t)i;
+            const unsigned long long f = (unsigned long long)((uint32_t)b->lit_code[sym] | (uint32_t)b->lit_len[sym] << 15);
+            sh.c.cl[i][k / 3] |= f << (20 * (k % 3));
+        }
+    }
+    for (int i = t; i < 4 * kStage64; i += kTile)
+        (&sh.c.stage[0][0])[i] = 0ull;
+
+    const uint16_t *tok = job.tok + (size_t)tix * kTokStride;
+    const uint32_t n_tok = coded && !(job.diag & 2u) ? job.n_tok[tix] : 0u;
+    // this wave's quarter: whole trips of 256 tokens
+    const uint32_t per_wave = ((n_tok + 4u * kTripToks - 1u) / (4u * kTripToks)) * kTripToks;
+    const uint32_t c0 = (uint32_t)wave * per_wave;
+    const uint32_t c1 = c0 + per_wave < n_tok ? c0 + per_wave : n_tok;
+    __threadfence_block();                          // the zeroed slots are in place before this workgroup ORs into them
+    __syncthreads();
+
+    // four consecutive tokens of this lane (8-byte aligned: kTokStride and the trips are multiples of 4)
+    auto load4 = [&](uint32_t i0) -> uint2 {
+        const uint32_t i = i0 + (uint32_t)lane * kLaneToks;
+        return i < c1 ? *reinterpret_cast<const uint2 *>(tok + i) : make_uint2(0u, 0u);
+    };
+    auto tok_of = [](uint2 v, int q) -> uint32_t { return ((q < 2 ? v.x : v.y) >> (16 * (q & 1))) & 0xffffu; };
+
+    // phase 1: the bits of this quarter in every stream
+    {
+        uint32_t acc[kGroup];
+#pragma unroll
+        for (int k = 0; k < kGroup; k++)
+            acc[k] = 0;
+        for (uint32_t i0 = (job.diag & 1u) ? c1 : c0; i0 < c1; i0 += kTripToks) {      // (diag 1: timing without phase 1)
+            const uint2 v = load4(i0);
+#pragma unroll
+            for (int q = 0; q < kLaneToks; q++) {
+                if (i0 + (uint32_t)lane * kLaneToks + (uint32_t)q >= c1)
+                    continue;
+                const TokFields f = tok_fields(tok_of(v, q));
+                const unsigned long long h0 = sh.c.cl[f.sym][0], h1 = sh.c.cl[f.sym][1];
+#pragma unroll
+                for (int k = 0; k < kGroup; k++)
+                    acc[k] += (cl_field(h0, h1, k) >> 15) + f.ne + (f.is_match ? (f.far ? dlen1[k] : dlen0[k]) : 0u);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kGroup; k++) {
+            const uint32_t tot = wave_scan_dpp(acc[k]);
+            if (lane == 63)
+                sh.chunk_bits[k][wave] = (coded >> k) & 1u ? tot : 0u;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kGroup; k++) {
+        const uint32_t b0 = sh.chunk_bits[k][0], b1 = sh.chunk_bits[k][1], b2 = sh.chunk_bits[k][2];
+        base[k] += wave == 0 ? 0u : wave == 1 ? b0 : wave == 2 ? b0 + b1 : b0 + b1 + b2;
+        base[k] = __builtin_amdgcn_readfirstlane(base[k]);
+    }
+
+    // phase 2: 256 tokens per trip, this wave alone
+    unsigned long long *stage = sh.c.stage[wave];
+    unsigned long long carry[kGroup];               // per stream: the unfinished last word of the previous trip (wave-uniform)
+#pragma unroll
+    for (int k = 0; k < kGroup; k++)
+        carry[k] = 0ull;
+    uint2 next = load4(c0);
+    for (uint32_t i0 = c0; i0 < c1; i0 += kTripToks) {
+        const uint2 v = next;
+        next = load4(i0 + kTripToks);               // (in front of this trip's stores: vmcnt is one in-order queue)
+        TokFields f[kLaneToks];
+        unsigned long long h0[kLaneToks], h1[kLaneToks];
+        bool have[kLaneToks];
+#pragma unroll
+        for (int q = 0; q < kLaneToks; q++) {
+            have[q] = i0 + (uint32_t)lane * kLaneToks + (uint32_t)q < c1;
+            f[q] = tok_fields(have[q] ? tok_of(v, q) : 0u);         // (past the end: a harmless symbol, no bits)
+            h0[q] = sh.c.cl[f[q].sym][0];
+            h1[q] = sh.c.cl[f[q].sym][1];
+        }
+#pragma unroll
+        for (int k = 0; k < kGroup; k++) {
+            if (!((coded >> k) & 1u))
+                continue;
+            // the lane's four tokens packed into a chunk of <= 4 x 41 = 164 bits
+            unsigned long long a0 = 0, a1 = 0, a2 = 0;
+            uint32_t off = 0;
+#pragma unroll
+            for (int q = 0; q < kLaneToks; q++) {
+                const uint32_t c = cl_field(h0[q], h1[q], k);
+                const uint32_t l = c >> 15;
+                const uint32_t nb = l + f[q].ne;                        // <= 20
+                const uint32_t d = f[q].is_match ? (f[q].far ? dcode1[k] : dcode0[k]) : 0u;
+                const uint32_t dl = f[q].is_match ? (f[q].far ? dlen1[k] : dlen0[k]) : 0u;
+                const uint32_t n = have[q] ? nb + dl : 0u;
+                const unsigned long long bits = n ? (unsigned long long)((c & 0x7fffu) | f[q].ev << l) | (unsigned long long)d << nb : 0ull;
+                // off <= 41 q: the token starts in word 0 or 1 of the chunk
+                const uint32_t s = off & 63u;
+                const unsigned long long lo = bits << s, hi = (bits >> 1) >> (63u - s);
+                if (q == 0) {
+                    a0 = bits;
+                }
+                else if (q == 1) {                  // off <= 41
+                    a0 |= lo;
+                    a1 |= hi;
+                }
+                else {                              // off <= 123
+                    const bool w1 = off >= 64u;
+                    a0 |= w1 ? 0ull : lo;
+                    a1 |= w1 ? lo : hi;
+                    a2 |= w1 ? hi : 0ull;
+                }
+                off += n;
+            }
+            // where the chunk goes: prefix sum of the lanes' bit counts (a trip's total is < 2^16)
+            const uint32_t incl = wave_scan_dpp(off);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t first = base[k];                             // this trip's first bit in the stream (wave-uniform)
+            // the unfinished last word of this stream's previous trip is the first word of this one
+            if (lane == 0)
+                stage[0] = carry[k];
+            if (!(job.diag & 4u)) {                                     // (diag 4: timing without the LDS atomics)
+                const uint32_t rel = (first & 63u) + incl - off;
+                const uint32_t w = rel >> 6, s = rel & 63u;
+                const unsigned long long v0 = a0 << s, v1 = a1 << s | (a0 >> 1) >> (63u - s),
+                                         v2 = a2 << s | (a1 >> 1) >> (63u - s), v3 = (a2 >> 1) >> (63u - s);
+                if (v0) atomicOr(&stage[w], v0);
+                if (v1) atomicOr(&stage[w + 1], v1);
+                if (v2) atomicOr(&stage[w + 2], v2);
+                if (v3) atomicOr(&stage[w + 3], v3);
+            }
+            // (one wave: LDS executes its instructions in order, the reads below see the atomics above)
+            // Words of this trip: the last one, if the trip does not end on a word boundary, stays with the wave
+            // (carry) -- except in the wave's last trip -- so that only the first word of a wave's first trip and
+            // the last word of its last trip are shared with anyone (the header, a neighbouring wave, the trailer)
+            // and need a global atomic; everything else is a plain 8-byte store.  (Two atomics per word-sharing
+            // trip were 0.10 of this kernel's 0.15 ms per noisy strip: profiles/r03.)
+            const uint32_t end = (first & 63u) + total;
+            const uint32_t n_words = (end + 63u) >> 6;                  // <= 165
+            const bool last_trip = i0 + kTripToks >= c1;
+            const bool keep_last = (end & 63u) != 0u && !last_trip;     // the last word is unfinished and this wave goes on
+            const uint32_t n_out = keep_last ? n_words - 1u : n_words;
+            unsigned long long kept = 0;
+            if (!(job.diag & 16u))                                      // (diag 16: timing without the write-out)
+                for (uint32_t w = (uint32_t)lane; w < n_words; w += 64u) {
+                    const unsigned long long val = stage[w];
+                    stage[w] = 0ull;
+                    if (w >= n_out) {
+                        kept = val;                 // one lane
+                        continue;
+                    }
+                    unsigned long long *dst = words[k] + (first >> 6) + w;
+                    if (job.diag & 32u)             // (diag 32: timing with the LDS half of the write-out only)
+                        continue;
+                    const bool shared = (w == 0u && i0 == c0) || (w == n_words - 1u && last_trip);
+                    if (shared && !(job.diag & 8u))     // (diag 8: timing with plain stores only)
+                        atomicOr(dst, val);
+                    else
+                        *dst = val;
+                }
+            if (keep_last) {
+                const uint32_t src = (n_words - 1u) & 63u;
+                carry[k] = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kept, (int)src) |
+                           (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(kept >> 32), (int)src) << 32;
+            }
+            else {
+                carry[k] = 0ull;
+            }
+            base[k] = first + total;
+        }
+    }
+    // trailers: the Adler-32 of the raster's tile, big endian, after the last (padded) byte
+    if ((uint32_t)t < nj && ((coded >> t) & 1u)) {
+        const uint32_t j = j0 + (uint32_t)t;
+        const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)j * tiles + tix) * kBookBytes);
+        const uint32_t adler = job.t.hist[((size_t)j * tiles + tix) * kHistWords + 290];
+        uint32_t *w = reinterpret_cast<uint32_t *>(job.t.arena + job.t.table[((size_t)j * tiles + tix) * 2]);
+        const uint32_t at = b->stream_bytes - 4u;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            const uint32_t byte = (adler >> (24 - 8 * i)) & 0xffu;
+            atomicOr(&w[(at + i) >> 2], byte << (8 * ((at + i) & 3u)));
+        }
+    }
+    if (stored_mask == 0)
+        return;
+
+    // stored fallback (incompressible tiles): the raster's bytes are val(class), two blocks of
+    // 32768 bytes; the classes are formed again from landcover + soil
+    __syncthreads();
+    for (int i = t; i < gcn10::kClassCodes * 256 / 4; i += kTile)
+        reinterpret_cast<uint32_t *>(sh.class_of)[i] = reinterpret_cast<const uint32_t *>(job.class_of)[i];
+    __syncthreads();
+    for (uint32_t k = 0; k < nj; k++) {
+        if (!((stored_mask >> k) & 1u))
+            continue;
+        const uint32_t j = j0 + k;
+        uint8_t *o = job.t.arena + job.t.table[((size_t)j * tiles + tix) * 2];
+        const uint32_t adler = job.t.hist[((size_t)j * tiles + tix) * kHistWords + 290];
+        if (t == 0) {
+            o[0] = 0x78;
+            o[1] = 0x01;
+            for (int blk = 0; blk < 2; blk++) {
+                uint8_t *h = o + 2 + blk * (5 + 32768);
+                h[0] = (uint8_t)(blk == 1);
+                h[1] = 0x00;
+                h[2] = 0x80;
+                h[3] = 0xff;
+                h[4] = 0x7f;
+            }
+            const uint32_t at = (uint32_t)kMaxStream - 4u;
+            o[at] = (uint8_t)(adler >> 24);
+            o[at + 1] = (uint8_t)(adler >> 16);
+            o[at + 2] = (uint8_t)(adler >> 8);
+            o[at + 3] = (uint8_t)adler;
+        }
+        const uint8_t *val = class_val + job.sel[j] * 256;
+        const uint32_t xc = (uint32_t)(t & 63) * 4u;
+        for (int i = 0; i < kTile / 4; i++) {
+            const int r = i * 4 + (t >> 6);
+            const uint32_t c4 = class_pixels4(job, tx * kTile + xc, ty * kTile + (uint32_t)r, sh.class_of);
+            uint8_t *dst = o + 2 + (r >> 7) * (5 + 32768) + 5 + (r & 127) * kTile + xc;
+            dst[0] = val[c4 & 0xffu];
+            dst[1] = val[(c4 >> 8) & 0xffu];
+            dst[2] = val[(c4 >> 16) & 0xffu];
+            dst[3] = val[c4 >> 24];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1165,11 +1522,14 @@ int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W,
     static_assert(sizeof(SharedFA) <= 80 * 1024, "two fused statistics workgroups per CU");
     static_assert(sizeof(SharedFA2) <= 80 * 1024, "two segment-parallel statistics workgroups (32 waves) per CU");
     static_assert(sizeof(SharedFC) <= 20 * 1024, "eight fused emit workgroups per CU");
+    static_assert(sizeof(SharedFC2) <= 16 * 1024, "ten wave-independent emit workgroups per CU by LDS");
     if (!ctx->fused_ready) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_stats_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SharedFA)));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_stats_seg_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SharedFA2)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_emit_wave_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SharedFC2)));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_emit_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SharedFC)));
         ctx->fused_ready = true;
@@ -1183,7 +1543,10 @@ int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W,
     if (rc)
         return rc;
     const uint32_t groups = (job.n_sel + kGroup - 1) / kGroup;
-    hipLaunchKernelGGL(fused_emit_kernel, dim3(positions, groups), dim3(kTile), sizeof(SharedFC), s, job);
+    if (ctx->fused_emit == 0)
+        hipLaunchKernelGGL(fused_emit_kernel, dim3(positions, groups), dim3(kTile), sizeof(SharedFC), s, job);
+    else
+        hipLaunchKernelGGL(fused_emit_wave_kernel, dim3(positions, groups), dim3(kTile), sizeof(SharedFC2), s, job);
     HIP_TRY(hipGetLastError());
     return GCN10_OK;
 }

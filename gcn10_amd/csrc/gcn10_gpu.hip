@@ -1556,6 +1556,7 @@ int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value)
         ctx->arena_segment_align = fresh.arena_segment_align;
         ctx->fused_diag = fresh.fused_diag;
         ctx->fused_parse = fresh.fused_parse;
+        ctx->fused_emit = fresh.fused_emit;
         ctx->inflate_diag = fresh.inflate_diag;
         ctx->single = fresh.single;
     }
@@ -1575,9 +1576,11 @@ int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value)
         ctx->deflate_wave_codes = value;
     else if (!strcmp(name, "arena_segment_align") && value >= 16 && value <= 4096 && (value & (value - 1)) == 0)
         ctx->arena_segment_align = value;
+    else if (!strcmp(name, "fused_emit") && (value == 0 || value == 1))
+        ctx->fused_emit = value;
     else if (!strcmp(name, "fused_parse") && (value == 0 || value == 1))
         ctx->fused_parse = value;
-    else if (!strcmp(name, "fused_diag") && value >= 0 && value < 32)
+    else if (!strcmp(name, "fused_diag") && value >= 0 && value < 64)
         ctx->fused_diag = value;
     else if (!strcmp(name, "inflate_diag") && value >= 0 && value < 4)
         ctx->inflate_diag = value;

@@ -72,6 +72,7 @@ struct gcn10_gpu_ctx {
     int arena_segment_align = 4096; // tile encoder: a raster's streams of a strip start at a multiple of this (16 .. 4096)
     int deflate_wave_codes = 1;     // pass B of the tile encoder: 1 = one wave per tile, 0 = one thread
     int fused_parse = 1;            // pass F-A of the fused encoder: 1 = one lane per 64-pixel segment (round 3), 0 = one lane per row
+    int fused_emit = 1;             // pass F-C of the fused encoder: 1 = every wave packs its own quarter of the tokens (round 3), 0 = lock step
     int fused_diag = 0;             // timing experiments only (streams become invalid): 2 = pass F-C
                                     // without its token trips (set-up cost alone)
     int inflate_diag = 0;           // timing experiments only (output invalid): 1 = copier idle, 2 = empty batches

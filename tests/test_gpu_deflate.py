@@ -193,9 +193,11 @@ def test_fused_encoder_full_block_width(engine, tables, pattern):
 @pytest.mark.parametrize("texture", ["natural", "patches", "iid", "runs", "rows", "constant", "stripes63"])
 def test_segment_parallel_parse_is_the_row_parse_bit_for_bit(engine, tables, texture):
     """Round 3: pass F-A with one lane per 64-pixel segment (speculative parse + entry offsets, option
-    fused_parse=1, the default) writes the same token stream as one lane per row (fused_parse=0): arena
-    bytes, stream table and bytes used are identical, for textures whose matches end inside, at and far
-    beyond segment boundaries (whole-row matches, runs of 63 / 64 / 65 pixels, vertical repeats)."""
+    fused_parse=1, the default) writes the same token stream as one lane per row (fused_parse=0), and pass
+    F-C with every wave packing its own quarter of the tokens (fused_emit=1, the default) the same bits as
+    the lock-step form: arena bytes, stream table and bytes used are identical in all four combinations, for
+    textures whose matches end inside, at and far beyond segment boundaries (whole-row matches, runs of
+    63 / 64 / 65 pixels, vertical repeats)."""
     import bench
     from gcn10_amd import host
     H, W = 512, 2 * 256 + 100
@@ -226,16 +228,20 @@ def test_segment_parallel_parse_is_the_row_parse_bit_for_bit(engine, tables, tex
     engine.prepare_tile(bufs[1].ptr, coarse.shape[1], coarse.shape[0], bufs[2].ptr, W)
     out = {}
     try:
-        for parse in (0, 1):
+        # (pass F-A form, pass F-C form): rounds 1-2 = (0, 0); round 3's defaults = (1, 1)
+        for parse, emit in ((0, 0), (1, 0), (0, 1), (1, 1)):
             engine.set_option("fused_parse", parse)
-            out[parse] = engine.deflate_fused(bufs[0].ptr, W, H, bufs[3].ptr)
+            engine.set_option("fused_emit", emit)
+            out[parse, emit] = engine.deflate_fused(bufs[0].ptr, W, H, bufs[3].ptr)
     finally:
         engine.set_option("defaults", 0)
         for b in bufs:
             b.close()
-    assert out[0][2] == out[1][2], "bytes used differ: %d vs %d" % (out[0][2], out[1][2])
-    assert np.array_equal(out[0][1], out[1][1])
-    assert np.array_equal(out[0][0], out[1][0])
+    ref = out[0, 0]
+    for key in ((1, 0), (0, 1), (1, 1)):
+        assert ref[2] == out[key][2], "%s: bytes used differ: %d vs %d" % (key, ref[2], out[key][2])
+        assert np.array_equal(ref[1], out[key][1]), key
+        assert np.array_equal(ref[0], out[key][0]), key
 
 
 def test_fused_encoder_shares_streams_where_drained_equals_undrained(engine, tables):

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--rows", type=int, default=1024)
     ap.add_argument("--diags", default="0,1,2,6")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--emits", default="1", help='pass F-C forms to time: 0 = lock step, 1 = every wave its own quarter')
     ap.add_argument("--parses", default="1", help='pass F-A forms to time: 0 = one lane per row, 1 = one lane per 64-px segment')
     a = ap.parse_args()
     W, H = 36000, a.rows
@@ -43,8 +44,10 @@ def main():
         cap = int(gpu.lib().gcn10_gpu_deflate_arena_bound(W, H, n))
         arena, table, cursor = e.alloc(cap), e.alloc(n * across * down * 8), e.alloc(8)
         e0, e1 = e.event_create(), e.event_create()
-        for parse, d in [(int(p_), int(v)) for p_ in a.parses.split(",") for v in a.diags.split(",")]:
+        for parse, emit, d in [(int(p_), int(e_), int(v)) for p_ in a.parses.split(",") for e_ in a.emits.split(",")
+                               for v in a.diags.split(",")]:
             e.set_option("fused_parse", parse)
+            e.set_option("fused_emit", emit)
             e.set_option("fused_diag", d)
             ms = []
             for rep in range(a.reps + 1):
@@ -55,9 +58,9 @@ def main():
                 e.event_sync(e1)
                 ms.append(e.elapsed_ms(e0, e1))
             used = int(e.download(cursor.ptr, (1,), dtype=np.uint64)[0])
-            res["ms"]["parse%d_diag%d" % (parse, d)] = round(min(ms[1:]), 3)
+            res["ms"]["parse%d_emit%d_diag%d" % (parse, emit, d)] = round(min(ms[1:]), 3)
             if d == 0:
-                res["arena_bytes_parse%d" % parse] = used
+                res["arena_bytes_parse%d_emit%d" % (parse, emit)] = used
         e.set_option("defaults", 0)
         for b in bufs + [arena, table, cursor]:
             b.close()
