@@ -47,9 +47,19 @@ namespace {
 // starts further back than the ring reaches is read from the tile's slot in HBM, where every byte
 // older than kFlush + 258 already is (copy_match).  16 KiB instead of 32 lets six streams share a CU
 // (a block's ~1300-1370 tiles then decode in one round of 1536 slots instead of 1024 + a ragged rest).
-constexpr int kWindow = 16384;
+// Round 3: the ring size is a build parameter (GCN10_INFLATE_WINDOW; flush unit = half of it, sub-batches of
+// the copier a quarter).  With 8 KiB a workgroup needs 15.6 KB of LDS instead of 23.6 and ten streams share a
+// CU instead of six -- tried so that the decoder of block N+1 would leave room for the encoder of block N in
+// the two-stage pipeline: no effect on the block rate (0.037-0.043 s per noisy block either way, three
+// alternating runs on one box), and the decoder alone is 0-9 % slower (more matches read back from HBM):
+// profiles/r03/inflate_window_ab.txt.  16 KiB stays the default.
+// Invariant (copy_match): kFlush + kSubCap + 258 <= kWindow.
+#ifndef GCN10_INFLATE_WINDOW
+#define GCN10_INFLATE_WINDOW 16384
+#endif
+constexpr int kWindow = GCN10_INFLATE_WINDOW;
 constexpr int kWindowMask = kWindow - 1;
-constexpr int kFlush = 8192;
+constexpr int kFlush = kWindow / 2;
 constexpr int kBatch = 64;              // token words per hand-over from the decoder to the copier
 constexpr int kCand = 4;               // candidate start bits per lane: a window of 64 * kCand bits
 constexpr int kLitRoot = 10;
@@ -434,8 +444,9 @@ __device__ __forceinline__ void copy_match(Shared &sh, Output &o, uint32_t len, 
     const uint32_t from = o.pos - dist;
     if (dist + ahead > (uint32_t)kWindow) {
         // the source starts before what the ring still holds: all of it has been flushed to the slot
-        // (from + len <= pos - kWindow + ahead + len <= flushed, since pos - flushed < kFlush + 4096 and
-        // ahead <= kSubCap) -- wait for those stores, read it back
+        // (from + len < flushed + kFlush + kSubCap - kWindow + len <= flushed: a sub-batch starts with fewer than
+        // kFlush bytes pending and ends at most kSubCap further, and kFlush + kSubCap + 258 <= kWindow)
+        // -- wait for those stores, read it back
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint8_t v[5];
 #pragma unroll
@@ -507,7 +518,7 @@ static_assert(sizeof(TileIn) == sizeof(gcn10_inflate_tile), "TileIn mirrors the 
 // Tokens the decoder wave hands to the copier wave, one word each (a stored run takes two):
 //   literals  how many (1..3) << 24 | their bytes, first one lowest
 //   match     0x80000000 | (length - 3) << 16 | (distance - 1)
-//   stored    0x40000000 | length (<= 4096), then a word with the offset of the bytes in the stream
+//   stored    0x40000000 | length (<= kWindow / 4), then a word with the offset of the bytes in the stream
 constexpr uint32_t kTokMatch = 0x80000000u, kTokStored = 0x40000000u;
 
 enum { kNeedHeader = 0, kInSymbols = 1, kInStored = 2, kDone = 3 };
@@ -756,7 +767,7 @@ __device__ __forceinline__ uint32_t decode_batch(Shared &sh, Decoder &d, uint32_
         if (d.state == (uint32_t)kInStored) {
             if (n + 2u > (uint32_t)kBatch)
                 break;
-            uint32_t len = d.stored_left < 4096u ? d.stored_left : 4096u;
+            uint32_t len = d.stored_left < (uint32_t)(kWindow / 4) ? d.stored_left : (uint32_t)(kWindow / 4);    // = kSubCap
             if (len > d.limit - d.pos)
                 len = d.limit - d.pos;
             if (len > 0) {
@@ -982,7 +993,7 @@ __device__ __forceinline__ uint32_t copy_batch_serial(Shared &sh, Output &o, con
 // A token carried out early only writes bytes of its own place, so the order of A, B and C among
 // tokens that do not read each other's output is free; C runs in stream order, and by then every
 // byte an earlier token produces is there.
-constexpr uint32_t kSubCap = 4096;
+constexpr uint32_t kSubCap = kWindow / 4;     // (declared near kWindow: kSubCapBytes)
 constexpr uint32_t kShortMatch = 8;
 
 __device__ __forceinline__ uint32_t copy_batch(Shared &sh, Output &o, const uint32_t *ring, uint32_t n,
@@ -1249,7 +1260,8 @@ int gcn10_gpu_inflate_tiles(gcn10_gpu_ctx *ctx, const uint8_t *comp_dev, const g
         HIP_TRY(hipMalloc(&ctx->inflate_ws, need));
         ctx->inflate_ws_cap = need;
     }
-    static_assert(sizeof(Shared) <= 26 * 1024, "six streams (twelve wavefronts) per CU of 160 KiB LDS");
+    static_assert(kWindow / 2 + kWindow / 4 + 258 <= kWindow && (kWindow & (kWindow - 1)) == 0 && kWindow >= 4096, "window invariant");
+    static_assert(sizeof(Shared) <= (kWindow == 8192 ? 16 : 26) * 1024, "ten (8 KiB ring) or six (16 KiB) streams per CU of 160 KiB LDS");
     hipStream_t s = as_stream(ctx, stream);
     uint8_t *scratch = reinterpret_cast<uint8_t *>(ctx->inflate_ws);
     hipLaunchKernelGGL(inflate_kernel, dim3((uint32_t)n_tiles), dim3(128), sizeof(Shared), s, comp_dev,

@@ -551,8 +551,12 @@ static int encode_block(struct worker *w, struct block_in *in)
         b->y0 = y0;
         b->rows = rows;
 
-        /* while this strip is in flight, hand the previous one to the sink */
-        if (s > 0 && drain_strip(w, &w->buf[(s - 1) % r->nbuf], tifs, W, H) != 0) {
+        /* While this strip is in flight, hand an earlier one to the sink: the one `drain_lag` strips back
+         * (default 2).  Draining waits for that strip's kernels and counts; with a lag of 1 (rounds 1-2) the
+         * worker had exactly one strip queued behind the running one and could submit the next only when the
+         * previous had finished -- the trace of round 3 shows the compute stream idle ~0.5 ms between strips
+         * whose kernels take 0.2-0.3 ms.  With 2 the queue holds two strips while the host waits. */
+        if (s >= r->drain_lag && drain_strip(w, &w->buf[(s - r->drain_lag) % r->nbuf], tifs, W, H) != 0) {
             rc = -1;
             goto out;
         }
@@ -798,6 +802,11 @@ static void *worker_main(void *arg)
         w->busy_seconds += now_seconds() - t0;
         w->blocks_done += in->outcome >= 0 ? 1 : 0;
         w->in_seq++;
+        /* steady state of this worker: from the end of its first block (buffers allocated and pinned, kernels
+         * loaded, workspaces grown) to the end of its last */
+        if (w->in_seq == 1)
+            w->t_first_done = now_seconds();
+        w->t_last_done = now_seconds();
         gcn10_input_release(w, in);
         if (atomic_load(&r->fatal))
             break;
@@ -902,6 +911,13 @@ int gcn10_run(const gcn10_run_options *opt)
 
         r->nbuf = n < 2 ? 2 : (n > MAX_NBUF ? MAX_NBUF : n);
     }
+    r->drain_lag = 2;
+    if (getenv("GCN10_DRAIN_LAG"))
+        r->drain_lag = atoi(getenv("GCN10_DRAIN_LAG"));
+    if (r->drain_lag < 1)
+        r->drain_lag = 1;
+    if (r->drain_lag > r->nbuf - 1)
+        r->drain_lag = r->nbuf - 1;     /* the strip whose buffer is reused next must have been drained */
 
     /* GPUs: one worker ("rank") each */
     r->gpu = gcn10_gpu_api_get(err, sizeof err);
@@ -1110,6 +1126,22 @@ int gcn10_run(const gcn10_run_options *opt)
                 if (r->workers[i].t_first_block > 0.0 && (first == 0.0 || r->workers[i].t_first_block < first))
                     first = r->workers[i].t_first_block;
             steady = first > 0.0 ? now_seconds() - first : 0.0;
+        }
+        {
+            /* blocks per second of every worker after its first block, added up: the rate a long run sees */
+            double rate = 0.0;
+
+            for (int i = 0; i < r->n_workers; i++) {
+                const struct worker *w = &r->workers[i];
+
+                if (w->in_seq > 1 && w->t_last_done > w->t_first_done)
+                    rate += (double)(w->in_seq - 1) / (w->t_last_done - w->t_first_done);
+            }
+            if (rate > 0.0) {
+                snprintf(msg, sizeof msg, "timing: steady state %.4f s per block (%.2f blocks per second: every worker's blocks "
+                         "after its first, which pays for buffers, pinning and workspaces)", 1.0 / rate, rate);
+                gcn10_log_message(log0, "INFO", msg, false);
+            }
         }
         snprintf(msg, sizeof msg, "timing: %d blocks, %.3f s wall (%.3f s after start-up), %d gpu worker(s)%s%s%s; worker seconds: "
                  "in blocks %.3f, reading landcover %.3f, waiting for gpu %.3f, waiting for sink %.3f, "

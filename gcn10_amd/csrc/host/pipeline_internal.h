@@ -108,6 +108,7 @@ struct worker {
     char pci_bus[64];
     double busy_seconds;
     double t_first_block;                   /* when this worker started its first block */
+    double t_first_done, t_last_done;       /* when it finished its first / its last block */
     double t_gpu_wait, t_sink_wait;         /* where the worker thread's time goes */
     double t_create, t_finish, t_device, t_in_wait;
     double t_read, t_soil, t_in_busy;       /* ... and the input thread's */
@@ -128,6 +129,7 @@ struct run {
     atomic_int fatal;                       /* a worker hit an MPI_Abort-class error */
     int strip_rows;                         /* "strip_rows" of the config, rounded up to whole tile rows */
     int nbuf;                               /* strip buffer sets per worker (GCN10_STRIP_BUFFERS, 2..8) */
+    int drain_lag;                          /* the strip handed to the sink while strip s is submitted: s - drain_lag */
     int deflate_level;
     bool null_sink;                         /* GCN10_SINK=null: no compression, no files */
     bool gpu_deflate;                       /* tiles are encoded on the GPU */

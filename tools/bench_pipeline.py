@@ -66,6 +66,11 @@ def main():
     t0 = time.time()
     if not reuse:
         build_world(a, wd, size, nb, px)
+    else:
+        # the block list is cheap and depends on --repeat: always as asked
+        tiffutil.write_block_shapefile(os.path.join(wd, "blocks"),
+                                       [(rep * nb + i + 1, 3.0 * i, 0.0, 3.0 * (i + 1), 3.0)
+                                        for rep in range(a.repeat) for i in range(nb)])
     with open(os.path.join(wd, "config.txt"), "w") as f:
         f.write("hysogs_data_path=%s/soil.tif\nesa_data_path=%s/esa.tif\nblocks_shp_path=%s/blocks.shp\n"
                 "lookup_table_path=%s\nlog_dir=%s/logs\nstrip_rows=%d\ndeflate_level=%d\ngpu_deflate=%d\n"
@@ -115,11 +120,13 @@ def run_modes(a, wd, size, nb, build_s):
             env["GCN10_SINK"] = "null"
         shutil.rmtree(os.path.join(wd, "logs"), ignore_errors=True)
         t0 = time.time()
-        out = subprocess.run([os.path.join(ROOT, "bin", "gcn10"), "-c", "config.txt", "-o", "--gpus", str(a.gpus)],
+        # GCN10_BIN: another build of the program (same-box A/B against an earlier round: tools/r03/run_vs_r02.sh)
+        out = subprocess.run([os.environ.get("GCN10_BIN") or os.path.join(ROOT, "bin", "gcn10"), "-c", "config.txt", "-o", "--gpus", str(a.gpus)],
                              cwd=wd, env=env, capture_output=True, text=True)
         wall = time.time() - t0
         log = open(os.path.join(wd, "logs", "rank_0.log")).read() if os.path.exists(os.path.join(wd, "logs", "rank_0.log")) else ""
         m = re.search(r"timing: (\d+) blocks, ([0-9.]+) s wall(?: \(([0-9.]+) s after start-up\))?", log)
+        ms = re.search(r"timing: steady state ([0-9.]+) s per block", log)
         done = int(m.group(1)) if m else 0
         secs = float(m.group(2)) if m else wall
         steady = float(m.group(3)) if m and m.group(3) else None
@@ -134,6 +141,8 @@ def run_modes(a, wd, size, nb, build_s):
                               "seconds_per_block": round(secs / done, 3) if done else None,
                               "seconds_after_startup": steady,
                               "steady_seconds_per_block": round(steady / done, 4) if done and steady else None,
+                              # every worker's blocks after its first (which pays for allocations and pinning)
+                              "after_first_block_seconds_per_block": float(ms.group(1)) if ms else None,
                               "steady_cn_gpx_per_s": round(done * size * size * n_rasters / steady / 1e9, 1) if steady else None,
                               "output_bytes": nbytes, "stderr_tail": out.stderr[-300:] if out.returncode else ""}
     print(json.dumps(res))
