@@ -32,8 +32,16 @@ static void on_bad_row(void *user, const char *message)
 /* once per rank.  0, or -1 where the reference calls MPI_Abort (src/cn.c:25, 32) */
 int gcn10_binding_setup(int rank, const char *lookup_dir)
 {
-    int n_dev = gcn10_gpu_device_count(), failed = -1;
+    int n_dev, failed = -1;
 
+    /* the library on the library path must be the one this file was compiled against (ABI 3: tile flags,
+     * one extent per raster and strip; include/gcn10_gpu.h) */
+    if (gcn10_gpu_abi_version() != GCN10_GPU_ABI_VERSION) {
+        fprintf(stderr, "libgcn10_gpu.so has ABI version %d, this binding was built for %d\n", gcn10_gpu_abi_version(),
+                GCN10_GPU_ABI_VERSION);
+        return -1;
+    }
+    n_dev = gcn10_gpu_device_count();
     if (n_dev <= 0 || gcn10_gpu_init(rank % n_dev, &ctx) != 0) {
         fprintf(stderr, "gpu: %s\n", gcn10_gpu_last_error());     /* no CPU fallback */
         return -1;

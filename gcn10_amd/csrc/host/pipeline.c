@@ -338,7 +338,10 @@ static int ensure_strip_buffers(struct worker *w, int W)
             const int k = w->run->sel[q];
 
             if (!w->run->gpu_deflate)
+            {
                 GPU_TRY(w, g->host_alloc(w->ctx, px, (void **)&b->h_out[k]));
+                atomic_fetch_add(&w->run->pinned_bytes, (long long)px);
+            }
             if (!w->fused)
                 GPU_TRY(w, g->malloc(w->ctx, px, (void **)&b->d_out[k]));
         }
@@ -356,6 +359,7 @@ static int ensure_strip_buffers(struct worker *w, int W)
                 b->h_arena_cap = b->arena_cap;
             b->h_arena_cap &= ~(size_t)4095;
             GPU_TRY(w, g->host_alloc(w->ctx, b->h_arena_cap + 4096, (void **)&b->h_arena));
+            atomic_fetch_add(&w->run->pinned_bytes, (long long)(b->h_arena_cap + 4096 + tiles * GCN10_N_RASTERS * 8));
             GPU_TRY(w, g->malloc(w->ctx, tiles * GCN10_N_RASTERS * 8, (void **)&b->d_table));
             GPU_TRY(w, g->host_alloc(w->ctx, tiles * GCN10_N_RASTERS * 8, (void **)&b->h_table));
             GPU_TRY(w, g->malloc(w->ctx, 8, (void **)&b->d_cursor));
@@ -390,6 +394,7 @@ int gcn10_ensure_pinned_on(struct worker *w, gcn10_gpu_ctx *ctx, void **p, size_
     *cap = 0;
     need += need / 8 + 4096;
     GPU_TRY(w, g->host_alloc(ctx, need, p));
+    atomic_fetch_add(&w->run->pinned_bytes, (long long)need);
     *cap = need;
     return 0;
 }
@@ -443,6 +448,12 @@ static int encode_block(struct worker *w, struct block_in *in)
     bool ok = false;
     double t_mark = now_seconds();
 
+    if (getenv("GCN10_TEST_FAIL_BLOCK") && atoi(getenv("GCN10_TEST_FAIL_BLOCK")) == block_id) {
+        /* test hook (tools/r03/run_rehearse_8gpu.sh): one worker meets an error of the kind the reference answers
+         * with MPI_Abort -- the whole run must stop and exit with code 1 (src/main.c:175, src/cn.c:25, 216) */
+        wlog(w, "ERROR", true, "malloc failed for block %d (GCN10_TEST_FAIL_BLOCK)", block_id);
+        return -1;
+    }
     /* output directories (src/cn.c:237-256) and the 18 files */
     for (int c = 0; c < 2 && !r->null_sink; c++) {
         char dir[64];
@@ -739,9 +750,9 @@ static int worker_setup(struct worker *w)
         pthread_cond_init(&w->buf[i].cv, NULL);
         w->buf[i].owner = w;
     }
-    bind_to_gpu_numa_node(w, w->index % r->n_devices);
-    if (g->init(w->index % r->n_devices, &w->ctx) != 0) {
-        wlog(w, "ERROR", true, "gpu %d: %s", w->index % r->n_devices, g->last_error());
+    bind_to_gpu_numa_node(w, (w->index % r->n_devices) % r->n_physical);
+    if (g->init(w->device, &w->ctx) != 0) {
+        wlog(w, "ERROR", true, "gpu %d: %s", w->device, g->last_error());
         return -1;
     }
     {
@@ -937,7 +948,17 @@ int gcn10_run(const gcn10_run_options *opt)
         int gpus = opt->gpus > 0 ? opt->gpus : (r->cfg.gpus > 0 ? r->cfg.gpus : n_dev);
         int per_gpu = r->cfg.workers_per_gpu > 0 ? r->cfg.workers_per_gpu : 2;
 
-        if (getenv("GCN10_OVERSUBSCRIBE")) {    /* tests: N workers on however few GPUs there are */
+        r->n_physical = n_dev;
+        if (getenv("GCN10_REHEARSE_GPUS") && atoi(getenv("GCN10_REHEARSE_GPUS")) > 0) {
+            /* dress rehearsal of an N-GPU node on the devices that are here: N logical GPUs with
+             * per_gpu workers each, one I/O pool, N "timing gpu" lines; logical GPU d runs on device
+             * d % n_dev.  Same code path as a real node from the block queue to the per-GPU lines. */
+            r->n_devices = atoi(getenv("GCN10_REHEARSE_GPUS"));
+            if (opt->gpus > 0 && opt->gpus < r->n_devices)
+                r->n_devices = opt->gpus;
+            r->n_workers = r->n_devices * per_gpu;
+        }
+        else if (getenv("GCN10_OVERSUBSCRIBE")) {    /* tests: N workers on however few GPUs there are */
             r->n_devices = n_dev;
             r->n_workers = gpus;
         }
@@ -1158,11 +1179,16 @@ int gcn10_run(const gcn10_run_options *opt)
             struct rusage ru;
 
             if (getrusage(RUSAGE_SELF, &ru) == 0) {
-                snprintf(msg, sizeof msg, "timing: host cpu seconds: user %.3f, system %.3f, over %.3f s wall; "
-                         "voluntary / involuntary context switches %ld / %ld",
+                const double cpu = (double)ru.ru_utime.tv_sec + ru.ru_utime.tv_usec * 1e-6 +
+                                   (double)ru.ru_stime.tv_sec + ru.ru_stime.tv_usec * 1e-6;
+
+                snprintf(msg, sizeof msg, "timing: host cpu seconds: user %.3f, system %.3f, over %.3f s wall (%.3f per block); "
+                         "voluntary / involuntary context switches %ld / %ld; pinned host memory allocated %.1f MB; "
+                         "peak resident set %.1f MB",
                          (double)ru.ru_utime.tv_sec + ru.ru_utime.tv_usec * 1e-6,
                          (double)ru.ru_stime.tv_sec + ru.ru_stime.tv_usec * 1e-6, now_seconds() - t_start,
-                         ru.ru_nvcsw, ru.ru_nivcsw);
+                         done_blocks > 0 ? cpu / done_blocks : 0.0, ru.ru_nvcsw, ru.ru_nivcsw,
+                         (double)atomic_load(&r->pinned_bytes) / 1e6, (double)ru.ru_maxrss / 1e3);
                 gcn10_log_message(log0, "INFO", msg, false);
             }
         }

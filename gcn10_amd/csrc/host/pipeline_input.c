@@ -134,7 +134,10 @@ static int ring_ensure(struct worker *w, size_t need)
     w->ring_cap = 0;
     need = (need + 4095) & ~(size_t)4095;
     for (int k = 0; k < N_RING; k++)
+    {
         GPU_IN(w, g->host_alloc(w->in_ctx, need, (void **)&w->h_ring[k]));
+        atomic_fetch_add(&w->run->pinned_bytes, (long long)need);
+    }
     w->ring_cap = need;
     return 0;
 }

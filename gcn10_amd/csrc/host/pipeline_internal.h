@@ -125,6 +125,7 @@ struct run {
     int n_workers;
     struct worker *workers;
     gcn10_pool *pool;
+    atomic_llong pinned_bytes;              /* pinned host memory asked for by all workers (allocations; regrowth counts twice) */
     atomic_int next_block;
     atomic_int fatal;                       /* a worker hit an MPI_Abort-class error */
     int strip_rows;                         /* "strip_rows" of the config, rounded up to whole tile rows */
@@ -137,7 +138,9 @@ struct run {
     bool gpu_inflate;                       /* DEFLATE landcover tiles are decoded on the GPU */
     bool direct_io;                         /* tile data is written with O_DIRECT */
     bool prefetch;                          /* input threads stage block N+1 while block N is encoded */
-    int n_devices;                          /* visible GPUs; worker i uses device i % n_devices */
+    int n_devices;                          /* GPUs of the run; worker i belongs to GPU i % n_devices */
+    int n_physical;                         /* ... and the devices behind them: GPU d is device d % n_physical (all the
+                                               same unless GCN10_REHEARSE_GPUS rehearses a bigger node on this one) */
     int outer_rank, outer_size;             /* this process among the processes of an mpirun / srun */
     unsigned cond_mask, table_mask;         /* the rasters this run produces ("conditions" / "lookups") */
     int n_sel;                              /* how many: popcount(cond_mask) * popcount(table_mask) */
