@@ -154,13 +154,19 @@ def _host_cpu():
     return {"model": model, "sockets": len(sockets) or None}
 
 
-def traffic_from_profiles(workload: str, field: str = "hbm_bytes_per_launch"):
+def traffic_from_profiles(workload: str, field: str = "hbm_bytes_per_launch", kernel: str = ""):
     """HBM bytes per launch from the committed PMC pass (profiles/pmc_traffic.json), or None.
     field="kernel": the kernel instantiation that pass measured (it is the launch shape the calibration
     chose on the profiling box, not necessarily the one this run times)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        rec = json.load(open(path)).get(workload)
+        doc = json.load(open(path))
+        rec = doc.get(workload)
+        if kernel and workload == "config2":
+            # round 3: the passes keep every single-raster variant the calibration launched
+            by = doc.get("config2_by_kernel", {}).get(kernel)
+            if by and by.get("hbm_bytes_per_launch"):
+                return by["hbm_bytes_per_launch"] if field == "hbm_bytes_per_launch" else kernel
         return rec.get(field) if rec else None
     except Exception:
         return None
@@ -673,9 +679,9 @@ def main(argv=None):
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          # the committed PMC passes were taken at the default shape only
-                         "traffic": traffic_from_profiles(args.workload)
+                         "traffic": traffic_from_profiles(args.workload, kernel=kname)
                          if (size == 36000 and strip == size and args.pattern == "iid") else None,
-                         "traffic_kernel": traffic_from_profiles(args.workload, "kernel")
+                         "traffic_kernel": traffic_from_profiles(args.workload, "kernel", kernel=kname)
                          if (size == 36000 and strip == size and args.pattern == "iid") else None,
                          "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes, not this run)",
                          # what ONE ordinary allocation gets: the median over the candidate rasters the untimed

@@ -53,6 +53,7 @@ def main():
                          "36001 px wide (SURVEY.md section 7), rows are not 16-byte aligned")
     ap.add_argument("--esa-compression", type=int, default=1,
                     help="TIFF compression of the landcover input: 1 none, 8 DEFLATE (like the ESA COGs), 5 LZW")
+    ap.add_argument("--esa-predictor", type=int, default=1, help="TIFF predictor of the landcover input (2 = horizontal differencing)")
     a = ap.parse_args()
     wd = a.workdir
     size, nb = a.size, a.blocks
@@ -89,7 +90,7 @@ def build_world(a, wd, size, nb, px):
     esa = np.concatenate([esa1] * nb, axis=1) if nb > 1 else esa1
     del esa1
     tiffutil.write_tiff(os.path.join(wd, "esa.tif"), esa, gt=[0.0, px, 0.0, 3.0, 0.0, -px],
-                        compression=a.esa_compression, tile=(1024, 1024), bigtiff=esa.size > 3 * 2**30)
+                        compression=a.esa_compression, predictor=a.esa_predictor, tile=(1024, 1024), bigtiff=esa.size > 3 * 2**30)
     del esa
     hs = coarse1.shape[0]
     if a.dual_soil_fraction >= 0.0:
@@ -136,6 +137,7 @@ def run_modes(a, wd, size, nb, build_s):
             if os.path.isdir(p):
                 nbytes += sum(os.path.getsize(os.path.join(p, f)) for f in os.listdir(p))
         mt = re.search(r"worker seconds: (.*)", log)
+        mc = re.search(r"host cpu seconds: user ([0-9.]+), system ([0-9.]+), over [0-9.]+ s wall \(([0-9.]+) per block\).*?pinned host memory allocated ([0-9.]+) MB; peak resident set ([0-9.]+) MB", log)
         res["modes"][mode] = {"rc": out.returncode, "worker_seconds": mt.group(1) if mt else None, "blocks_done": done, "seconds": round(secs, 3),
                               "cn_gpx_per_s": round(done * size * size * n_rasters / secs / 1e9, 3) if secs else None,
                               "seconds_per_block": round(secs / done, 3) if done else None,
@@ -144,6 +146,9 @@ def run_modes(a, wd, size, nb, build_s):
                               # every worker's blocks after its first (which pays for allocations and pinning)
                               "after_first_block_seconds_per_block": float(ms.group(1)) if ms else None,
                               "steady_cn_gpx_per_s": round(done * size * size * n_rasters / steady / 1e9, 1) if steady else None,
+                              "host_cpu_seconds_per_block": float(mc.group(3)) if mc else None,
+                              "host_cpu_user_system": [float(mc.group(1)), float(mc.group(2))] if mc else None,
+                              "pinned_MB": float(mc.group(4)) if mc else None, "peak_rss_MB": float(mc.group(5)) if mc else None,
                               "output_bytes": nbytes, "stderr_tail": out.stderr[-300:] if out.returncode else ""}
     print(json.dumps(res))
     for d in ("cn_rasters_drained", "cn_rasters_undrained", "logs"):
