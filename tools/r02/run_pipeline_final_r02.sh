@@ -1,5 +1,5 @@
 #!/bin/bash
-# the pipeline numbers of round 2 (same commands as tools/run_pipeline_final_r01.sh), one call
+# the pipeline numbers of round 2 (same commands as tools/r01/run_pipeline_final_r01.sh), one call
 set -e
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out

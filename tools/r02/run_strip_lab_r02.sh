@@ -1,6 +1,6 @@
 # same-box A/B of the single-raster strip kernel variants (tools/strip_lab.hip, interleaved rounds)
 # next to copy kernels, then the product library's own variants (tools/tune_strip.py) on the same box.
-# Usage: gpurun -- bash tools/run_strip_lab_r02.sh
+# Usage: gpurun -- bash tools/r02/run_strip_lab_r02.sh
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out

@@ -9,7 +9,7 @@
 # per-kernel rows.
 set -e
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r03_baseline
+O=$R/gpurun_out/r03_${1:-baseline}
 mkdir -p $O
 export TMPDIR=/tmp
 TAG=${1:-baseline}

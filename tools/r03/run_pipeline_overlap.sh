@@ -6,7 +6,7 @@ SINK=${2:-null}
 R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/r03_overlap
-python3 $R/tools/bench_pipeline.py --pattern $PATTERN --blocks 8 --repeat 2 --modes $SINK --keep --esa-compression 8 --workdir /tmp/gcn10_ov > $R/gpurun_out/r03_overlap/overlap_plain.json
+python3 $R/tools/bench_pipeline.py --pattern $PATTERN --blocks 8 --repeat 6 --modes $SINK --keep --esa-compression 8 --workdir /tmp/gcn10_ov > $R/gpurun_out/r03_overlap/overlap_plain.json
 cd /tmp/gcn10_ov
 rm -rf logs cn_rasters_drained cn_rasters_undrained
 GCN10_SINK=$SINK rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/r03_overlap/overlap_trace -- $R/bin/gcn10 -c config.txt -o > $R/gpurun_out/r03_overlap/overlap.log 2>&1
