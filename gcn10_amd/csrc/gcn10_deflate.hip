@@ -661,6 +661,20 @@ __device__ __forceinline__ uint32_t rle_run(int v, int n, uint32_t *out, uint32_
     return bits;
 }
 
+// bits rle_run() spends on a run of `n` equal code lengths `v`, without walking it
+__device__ __forceinline__ uint32_t rle_run_bits(int v, int n)
+{
+    if (v == 0) {
+        // runs of 11..138 zeros: symbol 18 (4 + 7 bits); 3..10: symbol 17 (4 + 3); fewer: 4 bits each
+        const int q = n / 138, rem = n - q * 138;
+        return (uint32_t)(q * 11 + (rem >= 11 ? 11 : rem >= 3 ? 7 : rem * 4));
+    }
+    // the length itself, then repeats of 3..6 (symbol 16: 4 + 2 bits), then what is left, one by one
+    const int vbits = v >= 10 && v < 16 ? 5 : 4;
+    const int left = n - 1, q = left / 6, rem = left - q * 6;
+    return (uint32_t)(vbits + q * 6 + (rem >= 3 ? 6 : rem * vbits));
+}
+
 __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel(const TileJob job)
 {
     __shared__ __attribute__((aligned(16))) WaveWork work[kWavesPerBlock];
@@ -683,6 +697,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
         return;
     }
 
+    // (timing experiments, option "codes_stop" = p + 1: leave after phase p; books and sizes of the last complete
+    // launch stay in the workspace, so the passes behind this one still see valid input)
+    const uint32_t stop_after = job.codes_stop ? job.codes_stop - 1u : 99u;
     // ---- statistics: lane holds symbols lane + 64 c ----
     uint32_t h[5];
 #pragma unroll
@@ -707,6 +724,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
     }
     m = uni(m);
 
+    if (stop_after == 0u)
+        return;                 // phase 0: statistics loaded, live symbols compacted
     uint32_t count[17];
 #pragma unroll
     for (int i = 0; i <= 16; i++)
@@ -755,7 +774,40 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
                 wave_sync();
             }
         }
+        if (stop_after == 1u)
+            return;             // phase 1: + bitonic sort
         // ---- two-queue Huffman merge; both queues live in registers ----
+        if (m <= 63u) {
+            // The usual case (a tile has a few dozen live symbols): one leaf and one internal node per lane, so
+            // a pick is two v_readlane, a scalar compare and two selects -- no LDS, no branch on which register
+            // holds the element.  Lanes that hold no leaf / no node yet carry an infinite weight, which makes the
+            // "queue is empty" tests of the general form below unnecessary.  (Timing switches, round 3: this loop
+            // was 49 of the kernel's 81 us per noisy strip in its general form.)
+            uint32_t lw = (uint32_t)lane < m ? w.keys[lane] >> 9 : 0xffffffffu;
+            uint32_t iw = 0xffffffffu;              // internal node k (k = 0 .. m-2), created in weight order
+            uint32_t pl = 0, pn = 0;                // parent of leaf `lane`, of internal node `lane`
+            uint32_t leaf = 0, inode = 0;
+            for (uint32_t made = 0; made + 1 < m; made++) {
+                uint32_t sum = 0;
+#pragma unroll
+                for (int two = 0; two < 2; two++) {
+                    const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)lw, (int)leaf);
+                    const uint32_t wn = (uint32_t)__builtin_amdgcn_readlane((int)iw, (int)inode);
+                    const bool take_leaf = wl <= wn;        // tie: the leaf, as below
+                    sum += take_leaf ? wl : wn;
+                    pl = take_leaf && (uint32_t)lane == leaf ? m + made : pl;
+                    pn = !take_leaf && (uint32_t)lane == inode ? m + made : pn;
+                    leaf += take_leaf ? 1u : 0u;
+                    inode += take_leaf ? 0u : 1u;
+                }
+                iw = (uint32_t)lane == made ? sum : iw;
+            }
+            if ((uint32_t)lane < m)
+                w.parent[lane] = (uint16_t)pl;
+            if ((uint32_t)lane + 1u < m)
+                w.parent[m + (uint32_t)lane] = (uint16_t)pn;
+        }
+        else {
         uint32_t lw0 = lane < (int)m ? w.keys[lane] >> 9 : 0u;
         uint32_t lw1 = lane + 64 < (int)m ? w.keys[lane + 64] >> 9 : 0u;
         uint32_t lw2 = lane + 128 < (int)m ? w.keys[lane + 128] >> 9 : 0u;
@@ -783,7 +835,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
             }
             lane_array_set(iw0, iw1, iw2, made, sum, lane);
         }
+        }
         wave_sync();
+        if (stop_after == 2u)
+            return;             // phase 2: + the merge
         // ---- leaf depths: every lane walks up from its leaves to the root ----
         const uint32_t root = 2 * m - 2;
         uint32_t depth[3];
@@ -846,6 +901,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
             }
         }
     }
+    if (stop_after == 3u)
+        return;                 // phase 3: + depths, counts per length, the 15-bit cap, lengths by rank
     // distance alphabet: codes 0 (distance 1) and 15 (distance 256)
     if (lane < 32)
         w.len[288 + lane] = 0;
@@ -897,6 +954,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
         body_bits += __shfl_xor(body_bits, off, 64);
     body_bits += n_near * dl0 + n_far * (dl15 + 6u);
 
+    if (stop_after == 4u)
+        return;                 // phase 4: + canonical codes, body size
     // ---- block header: fixed part by lane 0, the code lengths run-length coded in parallel ----
     for (int i = lane; i < 64; i += 64)
         w.hdr[i] = 0;
@@ -961,17 +1020,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
             }
             run_len = nxt - i;
         }
-        const uint32_t bits = start ? rle_run(v_at[c], (int)run_len, nullptr, 0) : 0u;
-        uint32_t incl = bits;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t up = __shfl_up(incl, off, 64);
-            if (lane >= off)
-                incl += up;
-        }
+        const uint32_t bits = start ? rle_run_bits(v_at[c], (int)run_len) : 0u;
+        const uint32_t incl = wave_scan_dpp(bits);
         if (start)
             rle_run(v_at[c], (int)run_len, w.hdr, run_pos + incl - bits);
-        run_pos += uni(__shfl(incl, 63, 64));
+        run_pos += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
     wave_sync();
     const uint32_t header_bits = run_pos;
@@ -1315,6 +1368,7 @@ int gcn10_gpu_deflate_strip(gcn10_gpu_ctx *ctx, const uint8_t *const *rasters_de
     if ((reinterpret_cast<uintptr_t>(arena_dev) & 15u) != 0)
         return fail(GCN10_E_INVAL, "gcn10_gpu_deflate_strip: arena must be 16-byte aligned");
     TileJob job;
+    job.codes_stop = (uint32_t)ctx->codes_stop;
     job.rasters = rasters_dev;
     job.arena = arena_dev;
     job.table = table_dev;

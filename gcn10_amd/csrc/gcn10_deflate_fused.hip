@@ -495,6 +495,9 @@ __global__ __launch_bounds__(kFA2Threads, 8) void fused_stats_seg_kernel(const F
     const uint32_t tix = blockIdx.x;
     const uint32_t ty = tix / job.t.across, tx = tix - ty * job.t.across;
     const uint8_t *class_val = job.class_of + gcn10::kClassCodes * 256;
+    // (timing experiments, option "fused_stats_stop" = p + 1: leave after phase p; the workspace keeps the results
+    // of the last complete launch, so the passes behind this one still see valid input)
+    const uint32_t stop_after = (job.diag >> 8) ? (job.diag >> 8) - 1u : 99u;
 
     for (int i = t; i < gcn10::kClassCodes * 256 / 4; i += kFA2Threads)
         reinterpret_cast<uint32_t *>(sh.class_of)[i] = reinterpret_cast<const uint32_t *>(job.class_of)[i];
@@ -539,6 +542,8 @@ __global__ __launch_bounds__(kFA2Threads, 8) void fused_stats_seg_kernel(const F
         }
     }
     __syncthreads();
+    if (stop_after == 0u)
+        return;                 // phase 0: class map + landcover / soil loads + class tile
     for (int i = t; i < 288; i += kFA2Threads)
         sh.a.lit_hist[i] = 0;
     if (t < 2)
@@ -571,6 +576,8 @@ __global__ __launch_bounds__(kFA2Threads, 8) void fused_stats_seg_kernel(const F
         if (row == 0 && seg == 0)
             near_ &= ~1ull;             // the tile's first byte has no predecessor
     }
+    if (stop_after == 1u)
+        return;                 // phase 1: + the two candidate masks
     sh.a.lead_n[row][seg] = (uint8_t)(~near_ ? __builtin_ctzll(~near_) : kSegPx);
     sh.a.lead_f[row][seg] = (uint8_t)(~far_ ? __builtin_ctzll(~far_) : kSegPx);
     __syncthreads();
@@ -592,6 +599,8 @@ __global__ __launch_bounds__(kFA2Threads, 8) void fused_stats_seg_kernel(const F
         }
     }
 
+    if (stop_after == 2u)
+        return;                 // phase 2: + pixels and weights per class, run by run
     // length of the run of `far ? far_ : near_` that starts at pixel p of this segment, followed into the
     // segments behind it
     auto ext_run = [&](bool far, int p) -> int {
@@ -687,6 +696,8 @@ __global__ __launch_bounds__(kFA2Threads, 8) void fused_stats_seg_kernel(const F
         if (sgm + 1 < kSegs)
             sh.a.exit_at[row][sgm] = (uint16_t)exit_over;
     }
+    if (stop_after == 3u)
+        return;                 // phase 3: + the parse (speculative + entry offsets)
     // statistics of the final parse
     const unsigned long long lits = ~covered;
     const uint32_t my_tokens = (uint32_t)__popcll(lits) + (uint32_t)__popcll(starts);
@@ -750,31 +761,45 @@ __global__ __launch_bounds__(kFA2Threads, 8) void fused_stats_seg_kernel(const F
     }
     __syncthreads();
 
-    // From here on: per class (thread = class), exactly as the row form.  Threads 256.. only keep the barriers.
-    const bool cls = t < 256;
-    const uint32_t lits_c = cls ? sh.a.lit_hist[t] : 0u;
+    if (stop_after == 4u)
+        return;                 // phase 4: + statistics, scan, token write-out
+    // From here on the tile is no longer needed (its memory holds the value histograms below), and the work is
+    // per (raster, class).  The row form does it with 256 threads, raster after raster (18 x 3 wave sums in a
+    // row, three rounds of six value histograms); here the 16 waves split the rasters.
+    // (a) Adler-32 sums and the (class, value) hash of every raster: wave wv takes rasters wv, wv + 16
+    if (t == 0)
+        sh.a.differ = 0;
     {
-        const uint32_t n = cls ? sh.a.n_c[t] : 0u;
-        const uint32_t w = cls ? sh.a.w_c[t] % 65521u : 0u;
-        const bool present = n != 0;
-        if (t < GCN10_N_RASTERS)
-            sh.a.sig[t] = 0;
-        if (t == 0)
-            sh.a.differ = 0;
-        __syncthreads();
-        if (cls)
-            for (uint32_t j = 0; j < job.n_sel; j++) {
-                const uint32_t v = class_val[job.sel[j] * 256 + t];
-                uint32_t h = present ? (((uint32_t)t * 0x9E3779B1u + v * 0x85EBCA6Bu + 0x27D4EB2Fu) * 0x165667B1u) : 0u;
-                h ^= h >> 15;
-                const uint32_t p1 = wave_sum64(n * v), p2 = wave_sum64(w * v), p3 = wave_sum64(h);
-                if (lane == 0) {
-                    atomicAdd(&sh.a.s1[j], p1);
-                    atomicAdd(&sh.a.s2[j], p2);
-                    atomicAdd(&sh.a.sig[j], p3);
+        const int wv = t >> 6;
+        for (uint32_t j = (uint32_t)wv; j < job.n_sel; j += kFA2Threads / 64) {
+            const uint8_t *val = class_val + job.sel[j] * 256;
+            uint32_t a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t c = (uint32_t)lane + 64u * (uint32_t)q;
+                const uint32_t n = sh.a.n_c[c];
+                if (n) {
+                    const uint32_t v = val[c];
+                    uint32_t h = (c * 0x9E3779B1u + v * 0x85EBCA6Bu + 0x27D4EB2Fu) * 0x165667B1u;
+                    h ^= h >> 15;
+                    a1 += n * v;
+                    a2 += (sh.a.w_c[c] % 65521u) * v;       // (<= 256 x 65520 x 255 < 2^32 over the tile)
+                    a3 += h;
                 }
             }
+            a1 = wave_sum64(a1);
+            a2 = wave_sum64(a2);
+            a3 = wave_sum64(a3);
+            if (lane == 0) {
+                sh.a.s1[j] = a1;
+                sh.a.s2[j] = a2;
+                sh.a.sig[j] = a3;
+            }
+        }
     }
+    const bool cls = t < 256;
+    // (b) rasters that cannot differ on this tile (see the row form): the hash proposes, a comparison class by
+    // class confirms
     {
         const bool present = cls && sh.a.n_c[t] != 0;
         __syncthreads();
@@ -803,56 +828,40 @@ __global__ __launch_bounds__(kFA2Threads, 8) void fused_stats_seg_kernel(const F
             sh.a.alias[t] = (q != 0xffu && !((sh.a.differ >> t) & 1u)) ? (kAliasFlag | q) : 0u;
         }
     }
-    // per raster: literal counts by VALUE, kGroup rasters per round; the 1024 threads write the statistics out
-    for (uint32_t j0 = 0; j0 < job.n_sel; j0 += kGroup) {
-        const uint32_t nj = job.n_sel - j0 < (uint32_t)kGroup ? job.n_sel - j0 : (uint32_t)kGroup;
-        if (cls)
-            for (uint32_t k = 0; k < nj; k++)
-                sh.a.H[k][t] = 0;
-        __syncthreads();
+    // (c) per raster: literal counts by VALUE, all rasters at once in the memory of the tile
+    uint32_t *HV = reinterpret_cast<uint32_t *>(sh.tile);           // [n_sel][256]
+    static_assert(GCN10_N_RASTERS * 256 * 4 <= kTile * kRowStride, "value histograms fit the tile's memory");
+    for (uint32_t i = (uint32_t)t; i < job.n_sel * 256u; i += kFA2Threads)
+        HV[i] = 0;
+    __syncthreads();
+    {
+        const uint32_t c = (uint32_t)t & 255u;
+        const uint32_t lits_c = sh.a.lit_hist[c];
         if (lits_c)
-            for (uint32_t k = 0; k < nj; k++)
-                atomicAdd(&sh.a.H[k][class_val[job.sel[j0 + k] * 256 + t]], lits_c);
-        __syncthreads();
-        for (uint32_t idx = (uint32_t)t; idx < nj * (uint32_t)kHistWords; idx += kFA2Threads) {
-            const uint32_t k = idx / (uint32_t)kHistWords;
-            const int i = (int)(idx - k * (uint32_t)kHistWords);
-            const uint32_t j = j0 + k;
-            uint32_t v;
-            if (i < 256)
-                v = sh.a.H[k][i];
-            else if (i == 256)
-                v = 1u;                             // end of block
-            else if (i < 288)
-                v = sh.a.lit_hist[i];               // match length symbols: the same for every raster
-            else if (i < 290)
-                v = sh.a.dist_hist[i - 288];
-            else if (i == 290)
-                v = (((65536u % 65521u + sh.a.s2[j] % 65521u) % 65521u) << 16) | ((1u + sh.a.s1[j]) % 65521u);
-            else if (i == 291)
-                v = sh.a.alias[j];
-            else
-                v = 0u;
-            job.t.hist[((size_t)j * tiles + tix) * kHistWords + i] = v;
-        }
-        __syncthreads();
+            for (uint32_t j = (uint32_t)t >> 8; j < job.n_sel; j += kFA2Threads / 256)
+                atomicAdd(&HV[j * 256u + class_val[job.sel[j] * 256 + c]], lits_c);
     }
-}
-
-// Inclusive prefix sum over the 64 lanes with DPP adds (no LDS traffic): three shifted adds of
-// the input give sums over 4 lanes, row_shr:4 / row_shr:8 complete the rows of 16, row_bcast:15
-// and row_bcast:31 carry the row totals on.
-__device__ __forceinline__ uint32_t wave_scan_dpp(uint32_t x)
-{
-    uint32_t r = x;
-    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);     // row_shr:1
-    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);     // row_shr:2
-    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x113, 0xf, 0xf, false);     // row_shr:3
-    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x114, 0xf, 0xe, false);     // row_shr:4, lanes 4..15
-    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x118, 0xf, 0xc, false);     // row_shr:8, lanes 8..15
-    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
-    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
-    return r;
+    __syncthreads();
+    for (uint32_t idx = (uint32_t)t; idx < job.n_sel * (uint32_t)kHistWords; idx += kFA2Threads) {
+        const uint32_t j = idx / (uint32_t)kHistWords;
+        const int i = (int)(idx - j * (uint32_t)kHistWords);
+        uint32_t v;
+        if (i < 256)
+            v = HV[j * 256u + (uint32_t)i];
+        else if (i == 256)
+            v = 1u;                             // end of block
+        else if (i < 288)
+            v = sh.a.lit_hist[i];               // match length symbols: the same for every raster
+        else if (i < 290)
+            v = sh.a.dist_hist[i - 288];
+        else if (i == 290)
+            v = (((65536u % 65521u + sh.a.s2[j] % 65521u) % 65521u) << 16) | ((1u + sh.a.s1[j]) % 65521u);
+        else if (i == 291)
+            v = sh.a.alias[j];
+        else
+            v = 0u;
+        job.t.hist[((size_t)j * tiles + tix) * kHistWords + i] = v;
+    }
 }
 
 constexpr int kStageWords = 88;         // 64 tokens x 41 bits, starting anywhere in the first word
@@ -1487,7 +1496,7 @@ int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W,
     job.class_of = ctx->d_class_of;
     job.hx_stride = ctx->hx_stride;
     job.hx_rows = ctx->hx_rows;
-    job.diag = (uint32_t)ctx->fused_diag;
+    job.diag = (uint32_t)ctx->fused_diag | (uint32_t)ctx->fused_stats_stop << 8;
     for (int r = 0; r < GCN10_N_RASTERS; r++)
         if ((cond_mask >> (r / 9)) & 1u && (table_mask >> (r % 9)) & 1u)
             job.sel[job.n_sel++] = (uint8_t)r;
@@ -1503,6 +1512,7 @@ int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W,
         return fail(GCN10_E_INVAL, "tile encoder: an arena of %zu bytes does not fit 32-bit stream offsets "
                                    "(use fewer rows per strip)", arena_cap);
     job.t.arena_cap = arena_cap;
+    job.t.codes_stop = (uint32_t)ctx->codes_stop;
     const uint32_t positions = job.t.across * job.t.down;
     const uint64_t nblocks = (uint64_t)positions * job.n_sel;
     job.t.n_tiles = (uint32_t)nblocks;

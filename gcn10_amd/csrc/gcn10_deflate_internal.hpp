@@ -64,6 +64,7 @@ struct TileJob {
     uint8_t *books;                     // [n_tiles][kBookBytes]   (pass B -> C)
     uint32_t W, rows, across, down, n_tiles;
     unsigned long long arena_cap;
+    uint32_t codes_stop;                // timing experiments only (option "codes_stop"): pass B leaves after phase (value - 1)
 };
 
 // per-tile statistics written by pass A: 288 literal/length counts, 2 distance
@@ -162,6 +163,23 @@ __device__ __forceinline__ int next_candidate(const RowMasks &m, int x)
         pos += 64 - b;
     }
     return kTile;
+}
+
+
+// Inclusive prefix sum over the 64 lanes with DPP adds (no LDS traffic): three shifted adds of
+// the input give sums over 4 lanes, row_shr:4 / row_shr:8 complete the rows of 16, row_bcast:15
+// and row_bcast:31 carry the row totals on.
+__device__ __forceinline__ uint32_t wave_scan_dpp(uint32_t x)
+{
+    uint32_t r = x;
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);     // row_shr:1
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);     // row_shr:2
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x113, 0xf, 0xf, false);     // row_shr:3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x114, 0xf, 0xe, false);     // row_shr:4, lanes 4..15
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x118, 0xf, 0xc, false);     // row_shr:8, lanes 8..15
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
+    return r;
 }
 
 

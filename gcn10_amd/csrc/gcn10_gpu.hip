@@ -1557,6 +1557,8 @@ int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value)
         ctx->fused_diag = fresh.fused_diag;
         ctx->fused_parse = fresh.fused_parse;
         ctx->fused_emit = fresh.fused_emit;
+        ctx->fused_stats_stop = fresh.fused_stats_stop;
+        ctx->codes_stop = fresh.codes_stop;
         ctx->inflate_diag = fresh.inflate_diag;
         ctx->single = fresh.single;
     }
@@ -1576,6 +1578,10 @@ int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value)
         ctx->deflate_wave_codes = value;
     else if (!strcmp(name, "arena_segment_align") && value >= 16 && value <= 4096 && (value & (value - 1)) == 0)
         ctx->arena_segment_align = value;
+    else if (!strcmp(name, "codes_stop") && value >= 0 && value <= 8)
+        ctx->codes_stop = value;
+    else if (!strcmp(name, "fused_stats_stop") && value >= 0 && value <= 8)
+        ctx->fused_stats_stop = value;
     else if (!strcmp(name, "fused_emit") && (value == 0 || value == 1))
         ctx->fused_emit = value;
     else if (!strcmp(name, "fused_parse") && (value == 0 || value == 1))

@@ -73,6 +73,8 @@ struct gcn10_gpu_ctx {
     int deflate_wave_codes = 1;     // pass B of the tile encoder: 1 = one wave per tile, 0 = one thread
     int fused_parse = 1;            // pass F-A of the fused encoder: 1 = one lane per 64-pixel segment (round 3), 0 = one lane per row
     int fused_emit = 1;             // pass F-C of the fused encoder: 1 = every wave packs its own quarter of the tokens (round 3), 0 = lock step
+    int codes_stop = 0;             // timing experiments only: pass B leaves after phase (value - 1)
+    int fused_stats_stop = 0;       // timing experiments only: pass F-A leaves after phase (value - 1)
     int fused_diag = 0;             // timing experiments only (streams become invalid): 2 = pass F-C
                                     // without its token trips (set-up cost alone)
     int inflate_diag = 0;           // timing experiments only (output invalid): 1 = copier idle, 2 = empty batches

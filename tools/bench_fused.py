@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--rows", type=int, default=1024)
     ap.add_argument("--diags", default="0,1,2,6")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--codes-stops", default="0", help='pass B leaves after phase (value - 1) (timing only; 0 = complete)')
+    ap.add_argument("--stats-stops", default="0", help='pass F-A leaves after phase (value - 1) (timing only; 0 = complete)')
     ap.add_argument("--emits", default="1", help='pass F-C forms to time: 0 = lock step, 1 = every wave its own quarter')
     ap.add_argument("--parses", default="1", help='pass F-A forms to time: 0 = one lane per row, 1 = one lane per 64-px segment')
     a = ap.parse_args()
@@ -44,8 +46,11 @@ def main():
         cap = int(gpu.lib().gcn10_gpu_deflate_arena_bound(W, H, n))
         arena, table, cursor = e.alloc(cap), e.alloc(n * across * down * 8), e.alloc(8)
         e0, e1 = e.event_create(), e.event_create()
-        for parse, emit, d in [(int(p_), int(e_), int(v)) for p_ in a.parses.split(",") for e_ in a.emits.split(",")
-                               for v in a.diags.split(",")]:
+        for parse, emit, d, stop, cstop in [(int(p_), int(e_), int(v), int(st), int(cs)) for p_ in a.parses.split(",")
+                                            for e_ in a.emits.split(",") for v in a.diags.split(",")
+                                            for st in a.stats_stops.split(",") for cs in a.codes_stops.split(",")]:
+            e.set_option("fused_stats_stop", stop)
+            e.set_option("codes_stop", cstop)
             e.set_option("fused_parse", parse)
             e.set_option("fused_emit", emit)
             e.set_option("fused_diag", d)
@@ -58,8 +63,9 @@ def main():
                 e.event_sync(e1)
                 ms.append(e.elapsed_ms(e0, e1))
             used = int(e.download(cursor.ptr, (1,), dtype=np.uint64)[0])
-            res["ms"]["parse%d_emit%d_diag%d" % (parse, emit, d)] = round(min(ms[1:]), 3)
-            if d == 0:
+            res["ms"]["parse%d_emit%d_diag%d%s%s" % (parse, emit, d, "_stop%d" % stop if stop else "",
+                                                     "_cstop%d" % cstop if cstop else "")] = round(min(ms[1:]), 3)
+            if d == 0 and stop == 0 and cstop == 0:
                 res["arena_bytes_parse%d_emit%d" % (parse, emit)] = used
         e.set_option("defaults", 0)
         for b in bufs + [arena, table, cursor]:
