@@ -1219,6 +1219,18 @@ __global__ __launch_bounds__(256) void untile_kernel(const TileIn *tiles, const 
         return;
     }
     const uint8_t *src = chunk + (size_t)tin.src_y * tin.chunk_w + tin.src_x;
+    // rows whose source and destination are 16-byte aligned (interior tiles of a window that starts on a multiple
+    // of 16 pixels): 16 bytes per lane, a 1024-pixel row in one wave instruction each way
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(out) | tin.chunk_w | dst_stride | tin.copy_w) & 15u) == 0u) {
+        const uint32_t w16 = tin.copy_w / 16u;
+        for (uint32_t y = blockIdx.y * 4u + (threadIdx.x >> 6); y < tin.copy_h; y += gridDim.y * 4u) {
+            const u32x4 *s = reinterpret_cast<const u32x4 *>(src + (size_t)y * tin.chunk_w);
+            u32x4 *d = reinterpret_cast<u32x4 *>(out + (size_t)y * dst_stride);
+            for (uint32_t i = threadIdx.x & 63u; i < w16; i += 64u)
+                __builtin_nontemporal_store(__builtin_nontemporal_load(s + i), d + i);
+        }
+        return;
+    }
     const uint32_t w4 = tin.copy_w / 4u;
     for (uint32_t y = blockIdx.y * 4u + (threadIdx.x >> 6); y < tin.copy_h; y += gridDim.y * 4u) {
         const uint8_t *s = src + (size_t)y * tin.chunk_w;
