@@ -110,7 +110,7 @@ static void put_tiles_job(void *arg)
     struct put_job *j = arg;
     const uint32_t *tab = j->b->h_table + (size_t)j->raster * (size_t)j->across * (size_t)j->down * 2;
     const size_t n = (size_t)j->across * (size_t)j->down;
-    const bool arrived = j->w->run->gpu->event_sync(j->w->ctx, j->b->ev_d2h) == 0;  /* the strip's compressed bytes */
+    const bool arrived = true;              /* (the strip's gate job has waited for the copy: strip_gate_job) */
     int *txs = malloc(n * sizeof *txs), *tys = malloc(n * sizeof *tys);
     const void **data = malloc(n * sizeof *data);
     uint32_t *sizes = malloc(n * sizeof *sizes), *rel = malloc(n * sizeof *rel);
@@ -160,6 +160,64 @@ static void put_tiles_job(void *arg)
         pthread_cond_broadcast(&j->b->cv);
     pthread_mutex_unlock(&j->b->mu);
     free(j);
+}
+
+/* the end of a raster's file: directory, close, rename */
+struct finish_job {
+    struct worker *w;
+    struct strip_buf *b;
+    gcn10_tiff_writer *tif;
+};
+
+static void finish_tiff_job(void *arg)
+{
+    struct finish_job *j = arg;
+    char err[1024] = "";
+
+    if (gcn10_tiff_finish(j->tif, err, sizeof err) != 0)
+        wlog(j->w, "ERROR", true, "%s", err);           /* "write error %d on %s", src/raster.c:221 */
+    pthread_mutex_lock(&j->b->mu);
+    if (--j->b->pending == 0)
+        pthread_cond_broadcast(&j->b->cv);
+    pthread_mutex_unlock(&j->b->mu);
+    free(j);
+}
+
+/* One job per strip waits for the strip's compressed bytes to arrive in pinned memory (ONE thread of the pool in
+ * hipEventSynchronize instead of one per raster, round 3) and then hands the rasters' extents to the pool. */
+struct gate_job {
+    struct worker *w;
+    struct strip_buf *b;
+    gcn10_tiff_writer *tifs[GCN10_N_RASTERS];
+    int ty0, across, down;
+};
+
+static void strip_gate_job(void *arg)
+{
+    struct gate_job *g = arg;
+    struct run *r = g->w->run;
+    const bool arrived = r->gpu->event_sync(g->w->ctx, g->b->ev_d2h) == 0;
+
+    if (!arrived)
+        atomic_store(&g->w->failed, true);
+    for (int q = 0; arrived && q < r->n_sel; q++) {       /* stream q of the table = the q-th selected raster */
+        struct put_job *j = malloc(sizeof *j);
+
+        if (!j) {
+            atomic_store(&g->w->failed, true);
+            break;
+        }
+        *j = (struct put_job){ g->w, g->b, g->tifs[r->sel[q]], q, g->ty0, g->across, g->down };
+        pthread_mutex_lock(&g->b->mu);
+        g->b->pending++;
+        pthread_mutex_unlock(&g->b->mu);
+        gcn10_pool_submit(r->pool, put_tiles_job, j);
+    }
+    pthread_mutex_lock(&g->b->mu);
+    if (--g->b->pending == 0)
+        pthread_cond_broadcast(&g->b->cv);
+    pthread_mutex_unlock(&g->b->mu);
+    free(g);
 }
 
 static void wait_sink(struct strip_buf *b)
@@ -235,18 +293,23 @@ static int drain_strip_inner(struct worker *w, struct strip_buf *b, gcn10_tiff_w
                 g->event_record(w->ctx, b->ev_d2h, w->s_d2h) != 0)
                 goto gpu_error;
         }
-        for (int q = 0; q < r->n_sel; q++) {       /* stream q of the table = the q-th selected raster */
-            struct put_job *j = malloc(sizeof *j);
+        {
+            struct gate_job *j = malloc(sizeof *j);
 
             if (!j) {
                 wlog(w, "ERROR", true, "malloc failed for tile job");
                 return -1;
             }
-            *j = (struct put_job){ w, b, tifs[r->sel[q]], q, b->y0 / TILE, across, down };
+            j->w = w;
+            j->b = b;
+            memcpy(j->tifs, tifs, sizeof j->tifs);
+            j->ty0 = b->y0 / TILE;
+            j->across = across;
+            j->down = down;
             pthread_mutex_lock(&b->mu);
             b->pending++;
             pthread_mutex_unlock(&b->mu);
-            gcn10_pool_submit(r->pool, put_tiles_job, j);
+            gcn10_pool_submit(r->pool, strip_gate_job, j);
         }
         (void)H;
         return 0;
@@ -434,6 +497,61 @@ static void output_path(char *out, size_t cap, const char *cond, const char *hc,
     }
 }
 
+/* output directories (src/cn.c:237-256) and the files of the run's rasters, for block `in` */
+int gcn10_create_outputs(struct worker *w, struct block_in *in)
+{
+    struct run *r = w->run;
+    char err[1024] = "";
+    double t_mark = now_seconds();
+
+    memset(in->tifs, 0, sizeof in->tifs);
+    in->tifs_ok = false;
+    if (r->null_sink) {
+        in->tifs_ok = true;
+        return 0;
+    }
+    for (int c = 0; c < 2; c++) {
+        char dir[64];
+
+        if (!(r->cond_mask & (1u << c)))
+            continue;
+        snprintf(dir, sizeof dir, "cn_rasters_%s", gcn10_conds[c]);
+        if (mkdir(dir, 0755) != 0 && errno != EEXIST) {
+            wlog(w, "ERROR", true, "failed to create output directory %s", dir);       /* src/cn.c:250 */
+            return -1;
+        }
+    }
+    for (int q = 0; q < r->n_sel; q++) {
+        const int k = r->sel[q];
+        char path[PATH_MAX];
+
+        output_path(path, sizeof path, gcn10_conds[k / 9], gcn10_hcs[(k % 9) / 3], gcn10_arcs[k % 3],
+                    in->block_id, r->opt.overwrite);
+        in->tifs[k] = gcn10_tiff_create(path, in->W, in->H, in->gt, gcn10_raster_georef(w->esa), err, sizeof err);
+        if (!in->tifs[k]) {
+            wlog(w, "ERROR", true, "%s", err);          /* save_raster logs and goes on, src/raster.c:220-223 */
+            gcn10_abort_outputs(in);
+            w->t_create += now_seconds() - t_mark;
+            return 1;
+        }
+        if (r->direct_io && r->gpu_deflate)
+            gcn10_tiff_set_direct(in->tifs[k], true);   /* best effort: a file system that refuses writes buffered */
+    }
+    in->tifs_ok = true;
+    w->t_create += now_seconds() - t_mark;
+    return 0;
+}
+
+void gcn10_abort_outputs(struct block_in *in)
+{
+    for (int k = 0; k < GCN10_N_RASTERS; k++) {
+        if (in->tifs[k])
+            gcn10_tiff_abort(in->tifs[k]);
+        in->tifs[k] = NULL;
+    }
+    in->tifs_ok = false;
+}
+
 /* The back half of process_block (src/cn.c:236-384) for a block whose input the input side has put on its
  * way to HBM.  Returns 0 (done, or skipped like the reference skips) or -1 for errors the
  * reference answers with MPI_Abort */
@@ -454,34 +572,11 @@ static int encode_block(struct worker *w, struct block_in *in)
         wlog(w, "ERROR", true, "malloc failed for block %d (GCN10_TEST_FAIL_BLOCK)", block_id);
         return -1;
     }
-    /* output directories (src/cn.c:237-256) and the 18 files */
-    for (int c = 0; c < 2 && !r->null_sink; c++) {
-        char dir[64];
-
-        if (!(r->cond_mask & (1u << c)))
-            continue;
-        snprintf(dir, sizeof dir, "cn_rasters_%s", gcn10_conds[c]);
-        if (mkdir(dir, 0755) != 0 && errno != EEXIST) {
-            wlog(w, "ERROR", true, "failed to create output directory %s", dir);       /* src/cn.c:250 */
-            rc = -1;
-            goto out;
-        }
-    }
-    for (int q = 0; q < r->n_sel && !r->null_sink; q++) {
-        const int k = r->sel[q];
-        char path[PATH_MAX];
-
-        output_path(path, sizeof path, gcn10_conds[k / 9], gcn10_hcs[(k % 9) / 3], gcn10_arcs[k % 3],
-                    block_id, r->opt.overwrite);
-        tifs[k] = gcn10_tiff_create(path, W, H, in->gt, gcn10_raster_georef(w->esa), err, sizeof err);
-        if (!tifs[k]) {
-            wlog(w, "ERROR", true, "%s", err);          /* save_raster logs and goes on, src/raster.c:220-223 */
-            goto out;
-        }
-        if (r->direct_io && r->gpu_deflate)
-            gcn10_tiff_set_direct(tifs[k], true);       /* best effort: a file system that refuses writes buffered */
-    }
-    w->t_create += now_seconds() - t_mark;
+    /* the 18 files were created by the input side (gcn10_create_outputs), one block ahead */
+    memcpy(tifs, in->tifs, sizeof tifs);
+    memset(in->tifs, 0, sizeof in->tifs);
+    if (!r->null_sink && !in->tifs_ok)
+        goto out;                       /* save_raster logs and goes on, src/raster.c:220-223: logged at creation */
     t_mark = now_seconds();
 
     /* device side of the block: the encoder waits (on the device) for the input side's copies and kernels */
@@ -613,18 +708,38 @@ out:
     else if (!ok && w->ctx)
         g->stream_sync(w->ctx, w->s_kernel);    /* a block given up half-way: its kernels may still be queued */
     t_mark = now_seconds();
-    for (int k = 0; k < GCN10_N_RASTERS; k++) {
-        if (!tifs[k])
-            continue;
-        if (ok) {
-            if (gcn10_tiff_finish(tifs[k], err, sizeof err) != 0) {
-                wlog(w, "ERROR", true, "%s", err);      /* "write error %d on %s", src/raster.c:221 */
+    {
+        /* directory, close and rename of the 18 files: side by side on the I/O pool (4 ms per block in a row) */
+        struct strip_buf *b0 = &w->buf[0];      /* its job counter is idle here: every strip has been drained */
+
+        for (int k = 0; k < GCN10_N_RASTERS; k++) {
+            struct finish_job *j;
+
+            if (!tifs[k])
+                continue;
+            if (!ok) {
+                gcn10_tiff_abort(tifs[k]);
+                tifs[k] = NULL;
+                continue;
             }
+            j = r->pool ? malloc(sizeof *j) : NULL;
+            if (!j) {
+                if (gcn10_tiff_finish(tifs[k], err, sizeof err) != 0)
+                    wlog(w, "ERROR", true, "%s", err);      /* "write error %d on %s", src/raster.c:221 */
+                tifs[k] = NULL;
+                continue;
+            }
+            *j = (struct finish_job){ w, b0, tifs[k] };
+            tifs[k] = NULL;
+            pthread_mutex_lock(&b0->mu);
+            b0->pending++;
+            pthread_mutex_unlock(&b0->mu);
+            gcn10_pool_submit(r->pool, finish_tiff_job, j);
         }
-        else {
-            gcn10_tiff_abort(tifs[k]);
-        }
-        tifs[k] = NULL;
+        pthread_mutex_lock(&b0->mu);
+        while (b0->pending > 0)
+            pthread_cond_wait(&b0->cv, &b0->mu);
+        pthread_mutex_unlock(&b0->mu);
     }
     w->t_finish += now_seconds() - t_mark;
     if (ok) {
@@ -810,6 +925,7 @@ static void *worker_main(void *arg)
         t0 = now_seconds();
         if (in->outcome == 0 && !atomic_load(&r->fatal) && encode_block(w, in) != 0)
             atomic_store(&r->fatal, 1);     /* where the reference calls MPI_Abort */
+        gcn10_abort_outputs(in);            /* files of a block that was not encoded after all (a no-op otherwise) */
         w->busy_seconds += now_seconds() - t0;
         w->blocks_done += in->outcome >= 0 ? 1 : 0;
         w->in_seq++;

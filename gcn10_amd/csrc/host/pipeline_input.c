@@ -430,7 +430,13 @@ static int fill_block(struct worker *w, struct block_in *in, int block_id)
             w->ring_busy[k] = false;
         return rc == -2 ? -1 : 1;
     }
-    return 0;
+    /* the block's 18 files, while the copies and the decoder run (the reference creates each raster's file
+     * inside save_raster, after computing it: src/raster.c:204; an existing raster of that name is untouched
+     * until this one is complete either way: files are written as <name>.part) */
+    rc = gcn10_create_outputs(w, in);
+    if (rc < 0)
+        return -1;
+    return 0;               /* (rc == 1: logged; the worker finds tifs_ok false and gives the block up) */
 }
 
 /* takes the next block of the queue and fills slot `in` with it; false at the end of the queue */
@@ -567,6 +573,7 @@ void gcn10_input_teardown(struct worker *w)
         for (int k = 0; k < N_IN; k++) {
             struct block_in *in = &w->in[k];
 
+            gcn10_abort_outputs(in);        /* a staged block the worker never took */
             if (in->h_coarse) g->host_free(w->in_ctx, in->h_coarse);
             if (in->h_ci) g->host_free(w->in_ctx, in->h_ci);
             if (in->h_cj) g->host_free(w->in_ctx, in->h_cj);

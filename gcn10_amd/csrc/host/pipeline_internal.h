@@ -70,6 +70,10 @@ struct block_in {
     size_t jobs_cap;
     size_t n_inflate;                       /* chunks whose status must be looked at (0: host reader) */
     gcn10_event_t ev_ready;                 /* recorded behind everything the block needs on the device */
+    /* the block's output files (src/cn.c:236-360: directories, names, the trailing-underscore rule), created by
+     * the input side while the block before is encoded: 18 open + truncate calls are 5-10 ms per block */
+    gcn10_tiff_writer *tifs[GCN10_N_RASTERS];
+    bool tifs_ok;                           /* all of the run's rasters have their file */
 };
 
 struct worker {
@@ -161,6 +165,10 @@ int gcn10_ensure_pinned_on(struct worker *w, gcn10_gpu_ctx *ctx, void **p, size_
  *   w->in[] slots in turn and marks them IN_READY (IN_END after the last one).
  * gcn10_input_next: the slot the worker encodes next (waits for it; without a thread, fills it right here);
  *   NULL at the end of the queue.  gcn10_input_release hands the slot back. */
+/* pipeline.c: the output files of a block (directories, names, overwrite rule); 0, 1 = a file could not be created
+ * (logged like save_raster logs, the block is given up), -1 = an output directory cannot be made (fatal, src/cn.c:250) */
+int gcn10_create_outputs(struct worker *w, struct block_in *in);
+void gcn10_abort_outputs(struct block_in *in);
 int gcn10_input_setup(struct worker *w);
 void gcn10_input_teardown(struct worker *w);
 int gcn10_input_start(struct worker *w);
