@@ -1588,7 +1588,7 @@ int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value)
         ctx->fused_parse = value;
     else if (!strcmp(name, "fused_diag") && value >= 0 && value < 64)
         ctx->fused_diag = value;
-    else if (!strcmp(name, "inflate_diag") && value >= 0 && value < 4)
+    else if (!strcmp(name, "inflate_diag") && value >= 0 && value < 8)
         ctx->inflate_diag = value;
     else if (!strcmp(name, "prefetch") && (value == -1 || value == 0 || value == 1))
         ctx->prefetch = value;

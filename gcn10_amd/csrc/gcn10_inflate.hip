@@ -997,7 +997,7 @@ constexpr uint32_t kSubCap = kWindow / 4;     // (declared near kWindow: kSubCap
 constexpr uint32_t kShortMatch = 8;
 
 __device__ __forceinline__ uint32_t copy_batch(Shared &sh, Output &o, const uint32_t *ring, uint32_t n,
-                                               const uint8_t *stream, int lane)
+                                               const uint8_t *stream, int lane, uint32_t diag = 0)
 {
     const uint32_t tk = (uint32_t)lane < n ? ring[lane] : 0u;
     const bool valid = (uint32_t)lane < n;
@@ -1042,6 +1042,8 @@ __device__ __forceinline__ uint32_t copy_batch(Shared &sh, Output &o, const uint
         }
         // C: the other matches, in order
         unsigned long long rest = __ballot(is_match && l > 0u && !early);
+        if (diag == 3u)
+            rest = 0ull;                // (timing: without the matches carried out one by one)
         const uint32_t pos0 = o.pos;
         while (rest != 0ull) {
             const int i = __builtin_ctzll(rest);
@@ -1053,15 +1055,20 @@ __device__ __forceinline__ uint32_t copy_batch(Shared &sh, Output &o, const uint
         }
         o.pos = pos0 + S < o.limit ? pos0 + S : o.limit;
         done += m;
-        if (o.pos - o.flushed >= (uint32_t)kFlush)
-            flush_half(sh, o, lane);
+        if (o.pos - o.flushed >= (uint32_t)kFlush) {
+            if (diag == 4u)
+                o.flushed += kFlush;    // (timing: without the flush to HBM)
+            else
+                flush_half(sh, o, lane);
+        }
     }
     return 0;
 }
 
 // One workgroup of two wavefronts per stream: wave 0 decodes bits into tokens, wave 1 carries
 // the tokens out; they swap halves of a small token ring at a barrier every kBatch tokens.
-// diag (gcn10_gpu_set_option "inflate_diag", timing experiments only, output invalid): 1 = the copier
+// diag (gcn10_gpu_set_option "inflate_diag", timing experiments only, output invalid; 3 = the copier skips the
+// matches it carries out one by one, 4 = it skips its flushes to HBM): 1 = the copier
 // carries nothing out, 2 = the decoder hands over empty batches after decoding them
 __global__ __launch_bounds__(128) void inflate_kernel(const uint8_t *comp, const TileIn *tiles, uint32_t n_tiles,
                                                       uint8_t *scratch, uint32_t slot_bytes, uint32_t *status,
@@ -1141,7 +1148,7 @@ __global__ __launch_bounds__(128) void inflate_kernel(const uint8_t *comp, const
         }
         else if (it > 0 && c_err == 0) {
             if (diag != 1u)
-                c_err = copy_batch(sh, o, sh.ring[cur ^ 1u], uniform(sh.count[cur ^ 1u]), comp + tin.in_off, lane);
+                c_err = copy_batch(sh, o, sh.ring[cur ^ 1u], uniform(sh.count[cur ^ 1u]), comp + tin.in_off, lane, diag);
         }
         __syncthreads();
         if (it >= uniform(sh.stop))

@@ -966,6 +966,68 @@ static void outer_from_env(int *rank, int *size)
     }
 }
 
+/* The reference ends with MPI_Barrier and one "processed N blocks on R ranks" line from rank 0
+ * (src/main.c:187-194).  The processes of an mpirun / srun launch share the log directory, not an MPI
+ * library: every process leaves "<log_dir>/.done_<job>_<rank>" with its counts when its workers have
+ * joined, and launcher rank 0 waits for all of them (GCN10_BARRIER_SECONDS, default 600) and logs the totals.
+ * <job> tells launches apart (the launcher's job id from the environment, else the parent process id). */
+static void closing_barrier(struct run *r, gcn10_log *log0)
+{
+    static const char *const job_vars[] = { "SLURM_JOB_ID", "OMPI_MCA_ess_base_jobid", "PMIX_NAMESPACE", "PMI_JOBID",
+                                            "GCN10_JOB_ID" };
+    char job[96] = "", path[PATH_MAX], msg[512];
+    const double limit = getenv("GCN10_BARRIER_SECONDS") ? atof(getenv("GCN10_BARRIER_SECONDS")) : 600.0;
+    FILE *f;
+
+    for (size_t i = 0; i < sizeof job_vars / sizeof job_vars[0] && !job[0]; i++)
+        if (getenv(job_vars[i]) && *getenv(job_vars[i]))
+            snprintf(job, sizeof job, "%s", getenv(job_vars[i]));
+    if (!job[0])
+        snprintf(job, sizeof job, "p%ld", (long)getppid());     /* the ranks of one mpirun share their parent */
+    for (char *c = job; *c; c++)
+        if (!((*c >= '0' && *c <= '9') || (*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z')))
+            *c = '_';
+    snprintf(path, sizeof path, "%s/.done_%s_%d", r->cfg.log_dir, job, r->outer_rank);
+    f = fopen(path, "w");
+    if (f) {
+        fprintf(f, "%d %d %d\n", r->n_blocks, r->n_workers, atomic_load(&r->fatal) ? 1 : 0);
+        fclose(f);
+    }
+    if (r->outer_rank != 0)
+        return;
+    {
+        int blocks = 0, ranks = 0, arrived = 0, failed = 0;
+        const double t0 = now_seconds();
+
+        for (int p = 0; p < r->outer_size; p++) {
+            int b = 0, w = 0, bad = 0;
+            bool got = false;
+
+            snprintf(path, sizeof path, "%s/.done_%s_%d", r->cfg.log_dir, job, p);
+            while (!got && now_seconds() - t0 < limit) {
+                f = fopen(path, "r");
+                if (f) {
+                    got = fscanf(f, "%d %d %d", &b, &w, &bad) == 3;
+                    fclose(f);
+                }
+                if (!got)
+                    usleep(2000);
+            }
+            if (got) {
+                arrived++;
+                blocks += b;
+                ranks += w;
+                failed += bad;
+                unlink(path);
+            }
+        }
+        snprintf(msg, sizeof msg, "all %d processes: processed %d blocks on %d ranks%s%s", r->outer_size, blocks, ranks,
+                 arrived < r->outer_size ? " (some processes did not report in time)" : "",
+                 failed ? " (a process ended with an error)" : "");
+        gcn10_log_message(log0, arrived < r->outer_size || failed ? "ERROR" : "INFO", msg, true);
+    }
+}
+
 struct row_error_ctx {
     gcn10_log *log;
 };
@@ -1237,6 +1299,8 @@ int gcn10_run(const gcn10_run_options *opt)
 
     snprintf(msg, sizeof msg, "processed %d blocks on %d ranks", r->n_blocks, r->n_workers);  /* src/main.c:191 */
     gcn10_log_message(log0, "INFO", msg, true);
+    if (r->outer_size > 1)
+        closing_barrier(r, log0);           /* MPI_Barrier + rank 0's summary, src/main.c:187-194 */
     {
         int done_blocks = 0;
         double busy = 0, rd = 0, gw = 0, sw = 0, so = 0, cr = 0, fi = 0, dv = 0, steady = 0, iw = 0, ib = 0;

@@ -207,13 +207,21 @@ def test_outer_launcher_ranks_take_round_robin_shares(tmp_path):
     """Started by mpirun / srun, process r of n takes blocks r, r+n, ... (src/main.c:171)."""
     _world(tmp_path, seed=22)
     (tmp_path / "ids.txt").write_text("101 102 103\n")
-    for rank in (0, 1):
-        out = _run(tmp_path, "-c", "config.txt", "-l", "ids.txt", env={"PMI_RANK": str(rank), "PMI_SIZE": "2"})
-        assert out.returncode == 0, out.stderr[-2000:]
+    # the two processes of the "launch" run side by side, as under mpirun; they end with the reference's closing
+    # barrier (src/main.c:187-194) through marker files in the log directory, and rank 0 logs the totals
+    env = dict(os.environ, PMI_SIZE="2", GCN10_JOB_ID="t22", GCN10_BARRIER_SECONDS="300")
+    procs = [subprocess.Popen([GCN10, "-c", "config.txt", "-l", "ids.txt"], cwd=str(tmp_path), text=True,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(env, PMI_RANK=str(rank)))
+             for rank in (1, 0)]
+    for p in procs:
+        _, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
     log0 = (tmp_path / "logs" / "rank_0.log").read_text()
     log1 = (tmp_path / "logs" / "rank_1.log").read_text()
     assert "process 0 of 2: 2 of 3 blocks" in log0 and "process 1 of 2: 1 of 3 blocks" in log1
     assert "processing block 101" in log0 and "processing block 103" in log0 and "processing block 102" in log1
+    assert "all 2 processes: processed 3 blocks on 2 ranks" in log0 and "all 2 processes" not in log1
+    assert not [f for f in os.listdir(tmp_path / "logs") if f.startswith(".done_")]
     assert len(os.listdir(tmp_path / "cn_rasters_drained")) == 27
 
 
