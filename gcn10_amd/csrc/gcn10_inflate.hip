@@ -47,15 +47,18 @@ namespace {
 // starts further back than the ring reaches is read from the tile's slot in HBM, where every byte
 // older than kFlush + 258 already is (copy_match).  16 KiB instead of 32 lets six streams share a CU
 // (a block's ~1300-1370 tiles then decode in one round of 1536 slots instead of 1024 + a ragged rest).
-// Round 3: the ring size is a build parameter (GCN10_INFLATE_WINDOW; flush unit = half of it, sub-batches of
-// the copier a quarter).  With 8 KiB a workgroup needs 15.6 KB of LDS instead of 23.6 and ten streams share a
-// CU instead of six -- tried so that the decoder of block N+1 would leave room for the encoder of block N in
-// the two-stage pipeline: no effect on the block rate (0.037-0.043 s per noisy block either way, three
-// alternating runs on one box), and the decoder alone is 0-9 % slower (more matches read back from HBM):
-// profiles/r03/inflate_window_ab.txt.  16 KiB stays the default.
+// Round 3: 8 KiB (GCN10_INFLATE_WINDOW; flush unit = half of it, sub-batches of the copier a quarter).  A
+// workgroup then needs 15.6 KB of LDS instead of 23.6: five decoder workgroups per CU (a block's 1 296 streams)
+// take 78 KB and leave room for a 77 KB tile workgroup of the encoder's pass F-A beside them -- with 16 KiB rings
+// the decoder of block N+1 and the encoder of block N, which the round-3 pipeline runs side by side, took turns
+// on every CU.  Measured in the pipeline, steady state, 72 blocks, three alternating runs on one box
+// (profiles/r03/inflate_window_pipeline_72_blocks.txt): noisy blocks 0.0268-0.0282 -> 0.0215-0.0239 s with two
+// workers per GPU (0.0304 -> 0.0265 with one), patchy ones unchanged (0.0099-0.0104).  The decoder alone is
+// 0-9 % slower with the smaller ring (more matches read back from HBM: inflate_window_ab.txt, whose 16-block
+// pipeline rows were start-up dominated and showed nothing).
 // Invariant (copy_match): kFlush + kSubCap + 258 <= kWindow.
 #ifndef GCN10_INFLATE_WINDOW
-#define GCN10_INFLATE_WINDOW 16384
+#define GCN10_INFLATE_WINDOW 8192
 #endif
 constexpr int kWindow = GCN10_INFLATE_WINDOW;
 constexpr int kWindowMask = kWindow - 1;
