@@ -449,6 +449,16 @@ struct BitWriter {
     }
 };
 
+// placement by pass F-C (fused encoder): every stream's slot size, summed per raster and 64 positions
+__device__ __forceinline__ void add_chunk_total(const TileJob &job, uint32_t tile, uint32_t bytes)
+{
+    if (job.chunk_tot) {
+        const uint32_t per_raster = job.across * job.down;
+        const uint32_t r = tile / per_raster, pos = tile - r * per_raster;
+        atomicAdd(&job.chunk_tot[r * job.n_chunks + (pos >> 6)], (bytes + (uint32_t)(kSlotAlign - 1)) & ~(uint32_t)(kSlotAlign - 1));
+    }
+}
+
 __global__ __launch_bounds__(kBuildThreads) void deflate_codes_kernel(const TileJob job)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -462,8 +472,8 @@ __global__ __launch_bounds__(kBuildThreads) void deflate_codes_kernel(const Tile
         // the fused encoder found this tile equal to another raster's: nothing to build
         book->stream_bytes = 0;
         book->slot = kAliasSlot;
-        job.table[(size_t)tile * 2] = kAliasSlot;
-        job.table[(size_t)tile * 2 + 1] = 0u;
+        job.sizes[(size_t)tile * 2] = kAliasSlot;
+        job.sizes[(size_t)tile * 2 + 1] = 0u;
         return;
     }
 
@@ -563,8 +573,9 @@ __global__ __launch_bounds__(kBuildThreads) void deflate_codes_kernel(const Tile
         bytes = (uint32_t)kMaxStream;           // stored fallback
     // (its place in the arena: deflate_place_kernel, the next launch, from the sizes in the table)
     book->stream_bytes = bytes;
-    job.table[(size_t)tile * 2] = 0u;
-    job.table[(size_t)tile * 2 + 1] = bytes;
+    job.sizes[(size_t)tile * 2] = 0u;
+    job.sizes[(size_t)tile * 2 + 1] = bytes;
+    add_chunk_total(job, tile, bytes);
 }
 
 // ------------------------------------------------------------------------
@@ -691,8 +702,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
         if (lane == 0) {
             book->stream_bytes = 0;
             book->slot = kAliasSlot;
-            job.table[(size_t)tile * 2] = kAliasSlot;
-            job.table[(size_t)tile * 2 + 1] = 0u;
+            job.sizes[(size_t)tile * 2] = kAliasSlot;
+            job.sizes[(size_t)tile * 2 + 1] = 0u;
         }
         return;
     }
@@ -1038,8 +1049,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
         // (its place in the arena: deflate_place_kernel, the next launch, from the sizes in the table)
         book->header_bits = header_bits;
         book->stream_bytes = bytes;
-        job.table[(size_t)tile * 2] = 0u;
-        job.table[(size_t)tile * 2 + 1] = bytes;
+        job.sizes[(size_t)tile * 2] = 0u;
+        job.sizes[(size_t)tile * 2 + 1] = bytes;
+        add_chunk_total(job, tile, bytes);
     }
 }
 
@@ -1065,13 +1077,22 @@ __device__ __forceinline__ uint32_t place_need(uint32_t mark, uint32_t bytes)
     return mark == kAliasSlot ? 0u : (bytes + (uint32_t)(kSlotAlign - 1)) & ~(uint32_t)(kSlotAlign - 1);
 }
 
+__device__ __forceinline__ unsigned long long seg_of_pad(const unsigned long long (&sg)[GCN10_N_RASTERS + 1], uint32_t r)
+{
+    unsigned long long v = 0;
+#pragma unroll
+    for (uint32_t q = 0; q <= (uint32_t)GCN10_N_RASTERS; q++)
+        v = q == r ? sg[q] : v;
+    return v;
+}
+
 __global__ __launch_bounds__(kPlaceThreads) void deflate_place_kernel(const TileJob job, uint32_t tiles_per_raster,
                                                                       uint32_t seg_align)
 {
     __shared__ unsigned long long wave_tot[kPlaceThreads / 64];
     __shared__ unsigned long long P[GCN10_N_RASTERS + 1];       // unaligned prefix at each raster's first stream
     __shared__ unsigned long long seg[GCN10_N_RASTERS + 1];     // where each raster's extent starts
-    constexpr uint32_t kMaxK = 48;                              // entries per thread held in registers (49 152 streams)
+    constexpr uint32_t kMaxK = 40;                              // entries per thread kept in registers (40 960 streams)
     const uint32_t t = threadIdx.x;
     const uint32_t n = job.n_tiles;
     const uint32_t n_rasters = n / tiles_per_raster;
@@ -1079,12 +1100,38 @@ __global__ __launch_bounds__(kPlaceThreads) void deflate_place_kernel(const Tile
     const uint32_t i0 = t * K < n ? t * K : n, i1 = i0 + K < n ? i0 + K : n;
     const uint2 *tab = reinterpret_cast<const uint2 *>(job.table);
 
-    unsigned long long sum = 0;
-    for (uint32_t i = i0; i < i1; i++) {
-        const uint2 e = tab[i];
-        sum += place_need(e.x, e.y);
+    // one pass over the table: the thread's entries stay in registers (K <= kMaxK: strips of up to 4 096 rows of a
+    // 36000-px block; larger launches re-read), its sum, and its sum up to the raster boundary it may contain
+    // (K < tiles_per_raster whenever a raster has more tiles than a thread has entries: at most one boundary)
+    uint32_t need[kMaxK];
+    unsigned long long sum = 0, sum_at_boundary = 0;
+    uint32_t boundary = 0xffffffffu;                            // the raster that starts inside this thread's range
+    const bool in_regs = K <= kMaxK && K < tiles_per_raster;
+    if (in_regs) {
+#pragma unroll
+        for (uint32_t k = 0; k < kMaxK; k++) {
+            need[k] = 0;
+            if (k < K && i0 + k < i1) {
+                const uint2 e = tab[i0 + k];
+                need[k] = place_need(e.x, e.y) | (e.x == kAliasSlot ? 0x80000000u : 0u);
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kMaxK; k++)
+            if (k < K && i0 + k < i1) {
+                if ((i0 + k) % tiles_per_raster == 0) {
+                    boundary = (i0 + k) / tiles_per_raster;
+                    sum_at_boundary = sum;
+                }
+                sum += need[k] & 0x7fffffffu;
+            }
     }
-    (void)kMaxK;
+    else {
+        for (uint32_t i = i0; i < i1; i++) {
+            const uint2 e = tab[i];
+            sum += place_need(e.x, e.y);
+        }
+    }
     // exclusive scan over the workgroup
     unsigned long long incl = sum;
 #pragma unroll
@@ -1102,7 +1149,11 @@ __global__ __launch_bounds__(kPlaceThreads) void deflate_place_kernel(const Tile
             base += wave_tot[w];
         total += wave_tot[w];
     }
-    {
+    if (in_regs) {
+        if (boundary != 0xffffffffu)
+            P[boundary] = base + sum_at_boundary;
+    }
+    else {
         unsigned long long running = base;
         for (uint32_t i = i0; i < i1; i++) {
             const uint2 e = tab[i];
@@ -1114,40 +1165,81 @@ __global__ __launch_bounds__(kPlaceThreads) void deflate_place_kernel(const Tile
     if (t == 0)
         P[n_rasters] = total;
     __syncthreads();
-    if (t == 0) {
+    // every thread works the extents out for itself (18 steps on LDS values: cheaper than a third barrier)
+    unsigned long long my_seg[GCN10_N_RASTERS + 1];
+    {
         const unsigned long long a = seg_align;
-        seg[0] = 0;
-        for (uint32_t r = 1; r <= n_rasters; r++) {
-            const unsigned long long end = seg[r - 1] + (P[r] - P[r - 1]);
-            seg[r] = r < n_rasters ? (end + a - 1) / a * a : end;
+        my_seg[0] = 0;
+#pragma unroll
+        for (uint32_t r = 1; r <= (uint32_t)GCN10_N_RASTERS; r++) {
+            const unsigned long long end = r <= n_rasters ? my_seg[r - 1] + (P[r] - P[r - 1]) : 0ull;
+            my_seg[r] = r < n_rasters ? (end + a - 1) / a * a : end;
         }
-        *job.cursor = seg[n_rasters];
+        if (t == 0) {
+            unsigned long long used = 0;
+#pragma unroll
+            for (uint32_t r = 0; r <= (uint32_t)GCN10_N_RASTERS; r++) {
+                seg[r] = my_seg[r];
+                used = r == n_rasters ? my_seg[r] : used;
+            }
+            *job.cursor = used;
+        }
     }
-    __syncthreads();
     {
         unsigned long long running = base;
-        for (uint32_t i = i0; i < i1; i++) {
-            const uint2 e = tab[i];
-            const uint32_t r = i / tiles_per_raster;
-            const uint32_t need = place_need(e.x, e.y);
-            if (e.x != kAliasSlot) {
-                const unsigned long long off = seg[r] + (running - P[r]);
-                const bool fits = off + need <= job.arena_cap;
-                job.table[(size_t)i * 2] = fits ? (uint32_t)off : 0xffffffffu;
-                if (!fits)
-                    job.table[(size_t)i * 2 + 1] = 0u;
+        const uint32_t r0 = i0 < n ? i0 / tiles_per_raster : 0u;
+        auto seg_of = [&](uint32_t r) -> unsigned long long {
+            unsigned long long v = 0;
+#pragma unroll
+            for (uint32_t q = 0; q <= (uint32_t)GCN10_N_RASTERS; q++)
+                v = q == r ? my_seg[q] : v;
+            return v;
+        };
+        if (in_regs) {
+            // (at most two rasters in a thread's range)
+            const unsigned long long sa = seg_of(r0), pa = P[r0 < n_rasters ? r0 : 0], sb = seg_of(r0 + 1),
+                                     pb = P[r0 + 1 <= n_rasters ? r0 + 1 : 0];
+#pragma unroll
+            for (uint32_t k = 0; k < kMaxK; k++)
+                if (k < K && i0 + k < i1) {
+                    const uint32_t i = i0 + k;
+                    const bool second = i / tiles_per_raster != r0;
+                    const uint32_t nd = need[k] & 0x7fffffffu;
+                    if (!(need[k] & 0x80000000u)) {
+                        const unsigned long long off = (second ? sb : sa) + (running - (second ? pb : pa));
+                        const bool fits = off + nd <= job.arena_cap;
+                        job.table[(size_t)i * 2] = fits ? (uint32_t)off : 0xffffffffu;
+                        if (!fits)
+                            job.table[(size_t)i * 2 + 1] = 0u;
+                    }
+                    running += nd;
+                }
+        }
+        else {
+            for (uint32_t i = i0; i < i1; i++) {
+                const uint2 e = tab[i];
+                const uint32_t r = i / tiles_per_raster;
+                const uint32_t nd = place_need(e.x, e.y);
+                if (e.x != kAliasSlot) {
+                    const unsigned long long off = seg_of(r) + (running - P[r]);
+                    const bool fits = off + nd <= job.arena_cap;
+                    job.table[(size_t)i * 2] = fits ? (uint32_t)off : 0xffffffffu;
+                    if (!fits)
+                        job.table[(size_t)i * 2 + 1] = 0u;
+                }
+                running += nd;
             }
-            running += need;
         }
     }
     // the pad between a raster's last stream and the next raster's extent reads as zeros, and so do the
-    // bytes from the last stream's end to the next multiple of the alignment (an O_DIRECT write reads them)
-    for (uint32_t r = 0; r < n_rasters; r++) {
-        const unsigned long long from = seg[r] + (P[r + 1] - P[r]);
-        unsigned long long to = r + 1 < n_rasters ? seg[r + 1] : (from + seg_align - 1) / seg_align * seg_align;
+    // bytes from the last stream's end to the next multiple of the alignment (an O_DIRECT write reads them):
+    // wave w zeroes behind rasters w, w + 16
+    for (uint32_t r = t >> 6; r < n_rasters; r += kPlaceThreads / 64) {
+        const unsigned long long from = seg_of_pad(my_seg, r) + (P[r + 1] - P[r]);
+        unsigned long long to = r + 1 < n_rasters ? seg_of_pad(my_seg, r + 1) : (from + seg_align - 1) / seg_align * seg_align;
         if (to > job.arena_cap)
             to = job.arena_cap;
-        for (unsigned long long o = from + (unsigned long long)t * 16u; o + 16u <= to; o += (unsigned long long)kPlaceThreads * 16u)
+        for (unsigned long long o = from + (unsigned long long)(t & 63u) * 16u; o + 16u <= to; o += 64u * 16u)
             *reinterpret_cast<gcn10::u32x4 *>(job.arena + o) = gcn10::u32x4{ 0u, 0u, 0u, 0u };
     }
 }
@@ -1314,7 +1406,7 @@ int deflate_workspace(gcn10_gpu_ctx *ctx, size_t need)
     return GCN10_OK;
 }
 
-int deflate_launch_codes(gcn10_gpu_ctx *ctx, const TileJob &job, uint32_t nblocks, hipStream_t s)
+int deflate_launch_codes(gcn10_gpu_ctx *ctx, const TileJob &job, uint32_t nblocks, hipStream_t s, bool place)
 {
     static_assert(sizeof(Work) * kBuildThreads <= 160 * 1024, "code construction slices must fit LDS");
     if (ctx->deflate_wave_codes) {
@@ -1332,8 +1424,9 @@ int deflate_launch_codes(gcn10_gpu_ctx *ctx, const TileJob &job, uint32_t nblock
         hipLaunchKernelGGL(deflate_codes_kernel, dim3((nblocks + kBuildThreads - 1) / kBuildThreads),
                            dim3(kBuildThreads), sizeof(Work) * kBuildThreads, s, job);
     }
-    hipLaunchKernelGGL(deflate_place_kernel, dim3(1), dim3(kPlaceThreads), 0, s, job, job.across * job.down,
-                       (uint32_t)ctx->arena_segment_align);
+    if (place)
+        hipLaunchKernelGGL(deflate_place_kernel, dim3(1), dim3(kPlaceThreads), 0, s, job, job.across * job.down,
+                           (uint32_t)ctx->arena_segment_align);
     HIP_TRY(hipGetLastError());
     return GCN10_OK;
 }
@@ -1372,6 +1465,9 @@ int gcn10_gpu_deflate_strip(gcn10_gpu_ctx *ctx, const uint8_t *const *rasters_de
     job.rasters = rasters_dev;
     job.arena = arena_dev;
     job.table = table_dev;
+    job.sizes = table_dev;          // pass B' places in the table itself
+    job.chunk_tot = nullptr;
+    job.n_chunks = 0;
     job.cursor = cursor_dev;
     job.W = (uint32_t)W;
     job.rows = (uint32_t)rows;

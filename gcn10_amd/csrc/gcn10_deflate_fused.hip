@@ -47,6 +47,7 @@ struct FusedJob {
     uint32_t *n_tok;                // [positions] its length, end-of-block token included
     uint32_t hx_stride, hx_rows;
     uint32_t diag;                  // gcn10_gpu_set_option("fused_diag"): timing experiments
+    uint32_t seg_align;             // every raster's extent of the strip starts at a multiple of this (option arena_segment_align)
     uint32_t n_sel;                 // selected rasters, ascending
     uint8_t sel[GCN10_N_RASTERS];
     TileJob t;
@@ -249,6 +250,10 @@ __global__ __launch_bounds__(kTile) void fused_stats_kernel(const FusedJob job)
     const uint32_t tix = blockIdx.x;
     const uint32_t ty = tix / job.t.across, tx = tix - ty * job.t.across;
     const uint8_t *class_val = job.class_of + gcn10::kClassCodes * 256;
+    // (pass B adds the stream sizes up per raster and 64 positions for pass F-C's placement: from zero)
+    if (job.t.chunk_tot && tix == 0u)
+        for (uint32_t i = (uint32_t)t; i < job.n_sel * job.t.n_chunks; i += blockDim.x)
+            job.t.chunk_tot[i] = 0u;
 
     for (int i = t; i < gcn10::kClassCodes * 256 / 4; i += kTile)
         reinterpret_cast<uint32_t *>(sh.class_of)[i] = reinterpret_cast<const uint32_t *>(job.class_of)[i];
@@ -495,6 +500,10 @@ __global__ __launch_bounds__(kFA2Threads, 8) void fused_stats_seg_kernel(const F
     const uint32_t tix = blockIdx.x;
     const uint32_t ty = tix / job.t.across, tx = tix - ty * job.t.across;
     const uint8_t *class_val = job.class_of + gcn10::kClassCodes * 256;
+    // (pass B adds the stream sizes up per raster and 64 positions for pass F-C's placement: from zero)
+    if (job.t.chunk_tot && tix == 0u)
+        for (uint32_t i = (uint32_t)t; i < job.n_sel * job.t.n_chunks; i += blockDim.x)
+            job.t.chunk_tot[i] = 0u;
     // (timing experiments, option "fused_stats_stop" = p + 1: leave after phase p; the workspace keeps the results
     // of the last complete launch, so the passes behind this one still see valid input)
     const uint32_t stop_after = (job.diag >> 8) ? (job.diag >> 8) - 1u : 99u;
@@ -1129,6 +1138,9 @@ struct SharedFC2 {
     };
     uint32_t chunk_bits[kGroup][4];         // bits of each wave's quarter, per stream
     uint32_t masks[2];
+    uint32_t r_tot[GCN10_N_RASTERS];        // arena bytes of every raster's streams of this strip (16-byte slots)
+    uint32_t r_pre[GCN10_N_RASTERS];        // ... of its positions before this one
+    uint32_t slot[kGroup];                  // where this position's streams of the group lie
 };
 
 // what a 16-bit token says: symbol, extra bits of a length, which distance
@@ -1169,20 +1181,98 @@ __global__ __launch_bounds__(kTile, 6) void fused_emit_wave_kernel(const FusedJo
     const uint32_t nj = job.n_sel - j0 < (uint32_t)kGroup ? job.n_sel - j0 : (uint32_t)kGroup;
     const uint8_t *class_val = job.class_of + gcn10::kClassCodes * 256;
 
+    // Where this position's streams go (round 3: pass B' folded in -- a launch of one workgroup and its kernel
+    // boundary were 16-18 us per strip).  Pass B left sizes[i] = { alias mark or 0, stream bytes } and added every
+    // stream's 16-byte-aligned size to chunk_tot[raster][position / 64].  The layout is raster-major, tiles of a
+    // raster in order, 16-byte slots, every raster's extent starting at a multiple of seg_align (a power of two):
+    // the offset of (raster j, this position) is the sum of the aligned totals of the rasters before j plus the sizes
+    // of raster j's earlier positions.  Every workgroup adds those up for itself: the chunk totals of the rasters up
+    // to its own (one load per lane for a 1024-row strip of a 3-degree block: 18 x 9 values) and the sizes of its own
+    // chunk of positions (at most 4.5 loads per lane) -- one memory latency, against the 61 KB table a workgroup
+    // would otherwise have to read.  It writes the offsets of ITS six streams into the table for the host and keeps
+    // them in LDS for itself.  The workgroups of position 0 zero the pads in front of their rasters' extents; the one
+    // of the last group also writes the bytes used.
+    {
+        const uint32_t jn = j0 + nj;                    // (an alias's original is an earlier raster, maybe of another group)
+        const uint32_t chunks = job.t.n_chunks, c = tix >> 6;
+        if (t < GCN10_N_RASTERS) {
+            sh.r_tot[t] = 0;
+            sh.r_pre[t] = 0;
+        }
+        __syncthreads();
+        for (uint32_t i = (uint32_t)t; i < jn * chunks; i += (uint32_t)kTile) {
+            const uint32_t v = job.t.chunk_tot[i];
+            const uint32_t r = i / chunks, cc = i - r * chunks;
+            if (v) {
+                atomicAdd(&sh.r_tot[r], v);
+                if (cc < c)
+                    atomicAdd(&sh.r_pre[r], v);
+            }
+        }
+        const uint2 *tab = reinterpret_cast<const uint2 *>(job.t.sizes);
+        for (uint32_t r = (uint32_t)wave; r < jn; r += 4u) {
+            const uint32_t pp = c * 64u + (uint32_t)lane;
+            uint32_t nd = 0;
+            if (pp < tix) {
+                const uint2 e = tab[(size_t)r * tiles + pp];
+                nd = e.x == kAliasSlot ? 0u : (e.y + (uint32_t)(kSlotAlign - 1)) & ~(uint32_t)(kSlotAlign - 1);
+            }
+            nd = wave_scan_dpp(nd);
+            if (lane == 63 && nd)
+                atomicAdd(&sh.r_pre[r], nd);
+        }
+    }
+    __syncthreads();
     // which rasters of the group have a slot, and which of those are stored
     uint32_t live, stored_mask;
     {
         int mine = 0, st = 0;
-        if ((uint32_t)t < nj) {
-            const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)(j0 + t) * tiles + tix) * kBookBytes);
-            mine = job.t.table[((size_t)(j0 + t) * tiles + tix) * 2] < kAliasSlot;      // neither "arena too small" nor an alias
-            st = mine && b->stream_bytes == (uint32_t)kMaxStream;
-            // an alias's table entry is its original's (placed by pass B', a launch ago)
-            const uint32_t al = job.t.hist[((size_t)(j0 + t) * tiles + tix) * kHistWords + 291];
-            if (al & kAliasFlag) {
-                const size_t from = ((size_t)(al & 0xffu) * tiles + tix) * 2, to = ((size_t)(j0 + t) * tiles + tix) * 2;
-                job.t.table[to] = job.t.table[from];
-                job.t.table[to + 1] = job.t.table[from + 1];
+        if (wave == 0) {
+            // extents: seg[j] = sum over r < j of the aligned totals (a scan over lanes 0..17)
+            const unsigned long long am = (unsigned long long)job.seg_align - 1ull;
+            const unsigned long long tot = (uint32_t)lane < job.n_sel ? sh.r_tot[lane] : 0u;
+            unsigned long long incl = (tot + am) & ~am;
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                const unsigned long long up = __shfl_up(incl, off, 64);
+                if (lane >= off)
+                    incl += up;
+            }
+            const unsigned long long seg = incl - ((tot + am) & ~am);      // where raster `lane`'s extent starts
+            const bool own = (uint32_t)t < nj;
+            const uint32_t j = own ? j0 + (uint32_t)t : 0u;
+            const uint32_t al = own ? job.t.hist[((size_t)j * tiles + tix) * kHistWords + 291] : 0u;
+            // an alias's table entry is its original's; the original may belong to another group's workgroup, so its
+            // offset is worked out here as well
+            const uint32_t src_j = al & kAliasFlag ? (al & 0xffu) : j;
+            const unsigned long long src_seg = __shfl(seg, (int)src_j, 64);
+            if (own) {
+                const size_t to = ((size_t)j * tiles + tix) * 2;
+                const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)j * tiles + tix) * kBookBytes);
+                const uint32_t bytes = al & kAliasFlag ? job.t.sizes[((size_t)src_j * tiles + tix) * 2 + 1] : b->stream_bytes;
+                const unsigned long long off = src_seg + sh.r_pre[src_j];
+                const uint32_t need = (bytes + (uint32_t)(kSlotAlign - 1)) & ~(uint32_t)(kSlotAlign - 1);
+                const bool fits = off + need <= job.t.arena_cap;
+                job.t.table[to] = fits ? (uint32_t)off : 0xffffffffu;
+                job.t.table[to + 1] = fits ? bytes : 0u;
+                sh.slot[t] = fits ? (uint32_t)off : 0xffffffffu;
+                mine = !(al & kAliasFlag) && fits;       // neither "arena too small" nor an alias
+                st = mine && bytes == (uint32_t)kMaxStream;
+            }
+            if (tix == 0u) {
+                // pads: behind each of my rasters' last stream up to the next extent's start (behind the last raster:
+                // up to the next multiple of the alignment: an O_DIRECT write reads that far); *cursor = bytes used
+                for (uint32_t k = 0; k < nj; k++) {
+                    const uint32_t r = j0 + k;
+                    const unsigned long long from = __shfl(seg, (int)r, 64) + __shfl(tot, (int)r, 64);
+                    unsigned long long to = (from + am) & ~am;
+                    if (to > job.t.arena_cap)
+                        to = job.t.arena_cap;
+                    for (unsigned long long o = from + (unsigned long long)lane * 16u; o + 16u <= to; o += 64u * 16u)
+                        *reinterpret_cast<u32x4 *>(job.t.arena + o) = u32x4{ 0u, 0u, 0u, 0u };
+                    if (r + 1u == job.n_sel && lane == 0)
+                        *job.t.cursor = from;
+                }
             }
         }
         live = (uint32_t)__ballot(mine);
@@ -1213,7 +1303,7 @@ __global__ __launch_bounds__(kTile, 6) void fused_emit_wave_kernel(const FusedJo
             continue;
         const uint32_t j = j0 + k;
         const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)j * tiles + tix) * kBookBytes);
-        uint32_t *w32 = reinterpret_cast<uint32_t *>(job.t.arena + job.t.table[((size_t)j * tiles + tix) * 2]);
+        uint32_t *w32 = reinterpret_cast<uint32_t *>(job.t.arena + sh.slot[k]);
         words[k] = reinterpret_cast<unsigned long long *>(w32);
         base[k] = __builtin_amdgcn_readfirstlane(b->header_bits);
         dcode0[k] = __builtin_amdgcn_readfirstlane((uint32_t)b->dist_code[0]);
@@ -1401,7 +1491,7 @@ __global__ __launch_bounds__(kTile, 6) void fused_emit_wave_kernel(const FusedJo
         const uint32_t j = j0 + (uint32_t)t;
         const Book *b = reinterpret_cast<const Book *>(job.t.books + ((size_t)j * tiles + tix) * kBookBytes);
         const uint32_t adler = job.t.hist[((size_t)j * tiles + tix) * kHistWords + 290];
-        uint32_t *w = reinterpret_cast<uint32_t *>(job.t.arena + job.t.table[((size_t)j * tiles + tix) * 2]);
+        uint32_t *w = reinterpret_cast<uint32_t *>(job.t.arena + sh.slot[t]);
         const uint32_t at = b->stream_bytes - 4u;
 #pragma unroll
         for (uint32_t i = 0; i < 4; i++) {
@@ -1422,7 +1512,7 @@ __global__ __launch_bounds__(kTile, 6) void fused_emit_wave_kernel(const FusedJo
         if (!((stored_mask >> k) & 1u))
             continue;
         const uint32_t j = j0 + k;
-        uint8_t *o = job.t.arena + job.t.table[((size_t)j * tiles + tix) * 2];
+        uint8_t *o = job.t.arena + sh.slot[k];
         const uint32_t adler = job.t.hist[((size_t)j * tiles + tix) * kHistWords + 290];
         if (t == 0) {
             o[0] = 0x78;
@@ -1497,6 +1587,7 @@ int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W,
     job.hx_stride = ctx->hx_stride;
     job.hx_rows = ctx->hx_rows;
     job.diag = (uint32_t)ctx->fused_diag | (uint32_t)ctx->fused_stats_stop << 8;
+    job.seg_align = (uint32_t)ctx->arena_segment_align;
     for (int r = 0; r < GCN10_N_RASTERS; r++)
         if ((cond_mask >> (r / 9)) & 1u && (table_mask >> (r % 9)) & 1u)
             job.sel[job.n_sel++] = (uint8_t)r;
@@ -1514,13 +1605,18 @@ int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W,
     job.t.arena_cap = arena_cap;
     job.t.codes_stop = (uint32_t)ctx->codes_stop;
     const uint32_t positions = job.t.across * job.t.down;
+    // (pass F-C adds a raster's stream sizes up in 32 bits; with the 4 GB arena limit above only a strip far beyond
+    // any arena can get here)
+    if ((uint64_t)positions * (uint64_t)(kMaxStream + kSlotAlign) >= 0xffffffffull)
+        return fail(GCN10_E_INVAL, "tile encoder: %u tile positions in one strip (use fewer rows per strip)", positions);
     const uint64_t nblocks = (uint64_t)positions * job.n_sel;
     job.t.n_tiles = (uint32_t)nblocks;
 
     // workspace: statistics + code books per (raster, tile), token tiles + match starts per position
     const size_t stats_bytes = ((size_t)nblocks * ((size_t)kHistWords * 4 + (size_t)kBookBytes) + 255) & ~(size_t)255;
     const size_t tok_bytes = (size_t)positions * kTokStride * sizeof(uint16_t);
-    const size_t need = stats_bytes + tok_bytes + (size_t)positions * sizeof(uint32_t);
+    const size_t ntok_bytes = ((size_t)positions * sizeof(uint32_t) + 15) & ~(size_t)15;
+    const size_t need = stats_bytes + tok_bytes + ntok_bytes + (size_t)nblocks * 8 + (size_t)job.n_sel * ((positions + 63u) / 64u) * 4;
     rc = gcn10::deflate_workspace(ctx, need);
     if (rc)
         return rc;
@@ -1528,6 +1624,14 @@ int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W,
     job.t.books = reinterpret_cast<uint8_t *>(ctx->deflate_ws) + (size_t)nblocks * kHistWords * 4;
     job.tok = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(ctx->deflate_ws) + stats_bytes);
     job.n_tok = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(ctx->deflate_ws) + stats_bytes + tok_bytes);
+    // the wave-independent pass F-C places the streams itself, every workgroup from all the sizes: those must not be
+    // the table the workgroups write the offsets to
+    job.t.sizes = table_dev;
+    if (ctx->fused_emit != 0) {
+        job.t.sizes = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(ctx->deflate_ws) + stats_bytes + tok_bytes + ntok_bytes);
+        job.t.chunk_tot = job.t.sizes + (size_t)nblocks * 2;        // zeroed by pass F-A, added to by pass B
+        job.t.n_chunks = (positions + 63u) / 64u;
+    }
 
     static_assert(sizeof(SharedFA) <= 80 * 1024, "two fused statistics workgroups per CU");
     static_assert(sizeof(SharedFA2) <= 80 * 1024, "two segment-parallel statistics workgroups (32 waves) per CU");
@@ -1549,7 +1653,8 @@ int gcn10_gpu_deflate_fused_strip(gcn10_gpu_ctx *ctx, const uint8_t *esa, int W,
         hipLaunchKernelGGL(fused_stats_kernel, dim3(positions), dim3(kTile), sizeof(SharedFA), s, job);
     else
         hipLaunchKernelGGL(fused_stats_seg_kernel, dim3(positions), dim3(kFA2Threads), sizeof(SharedFA2), s, job);
-    rc = gcn10::deflate_launch_codes(ctx, job.t, (uint32_t)nblocks, s);
+    // (pass B' as a launch of its own only for the lock-step form of pass F-C: the wave-independent form places its streams itself)
+    rc = gcn10::deflate_launch_codes(ctx, job.t, (uint32_t)nblocks, s, ctx->fused_emit == 0);
     if (rc)
         return rc;
     const uint32_t groups = (job.n_sel + kGroup - 1) / kGroup;

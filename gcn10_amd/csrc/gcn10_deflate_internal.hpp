@@ -59,6 +59,10 @@ struct TileJob {
     const uint8_t *const *rasters;      // device array of raster strip pointers
     uint8_t *arena;
     uint32_t *table;                    // [n_rasters][tiles][2] = offset, size
+    uint32_t *sizes;                    // [n_rasters][tiles][2] = alias mark or 0, bytes: what pass B leaves for the placement
+                                        // (the table itself when pass B' places; a workspace array when pass F-C does)
+    uint32_t *chunk_tot;                // [n_rasters][n_chunks] or null: 16-byte-aligned stream bytes of each 64 positions of a raster
+    uint32_t n_chunks;                  // (pass F-C places from these: fused encoder, wave-independent emit)
     unsigned long long *cursor;
     uint32_t *hist;                     // [n_tiles][kHistWords]   (pass A -> B)
     uint8_t *books;                     // [n_tiles][kBookBytes]   (pass B -> C)
@@ -191,8 +195,8 @@ using gcn10_deflate::TileJob;
 // Grows the context's encoder workspace (statistics, code books, token tiles) to `need` bytes.
 int deflate_workspace(gcn10_gpu_ctx *ctx, size_t need);
 // Pass B for `nblocks` (raster, tile) pairs whose statistics are in job.hist: code books to job.books,
-// arena slots reserved through job.cursor / job.table.
-int deflate_launch_codes(gcn10_gpu_ctx *ctx, const TileJob &job, uint32_t nblocks, hipStream_t s);
+// sizes to job.table; with `place`, pass B' (deflate_place_kernel) behind it lays the streams out in the arena.
+int deflate_launch_codes(gcn10_gpu_ctx *ctx, const TileJob &job, uint32_t nblocks, hipStream_t s, bool place = true);
 
 }  // namespace gcn10
 

@@ -244,6 +244,57 @@ def test_segment_parallel_parse_is_the_row_parse_bit_for_bit(engine, tables, tex
         assert np.array_equal(ref[0], out[key][0]), key
 
 
+@pytest.mark.parametrize("seg_align", [4096, 16])
+def test_streams_placed_by_the_bit_packing_pass_lie_where_the_placement_pass_puts_them(engine, tables, seg_align):
+    """Round 3: the wave-independent pass F-C places its streams itself (chunk totals from pass B, no pass B'
+    launch).  A strip of 992 tile positions (16 chunks of 64: more chunk totals than a workgroup has lanes),
+    ragged right edge, half of it without dual soil classes (aliases whose original belongs to another
+    group's workgroup): table, arena bytes and bytes used equal those of the lock-step form behind pass B'."""
+    import bench
+    from gcn10_amd import host
+    H, W = 31 * 256, 31 * 256 + 17
+    rng = np.random.default_rng(77)
+    esa = np.ascontiguousarray(np.tile(bench.synth_block(5, 2048, "patches")[0], (4, 4))[:H, :W])
+    hsy, hsx = H // 25 + 2, W // 25 + 2
+    coarse = rng.choice(np.array([1, 2, 3, 4], np.uint8), size=(hsy, hsx))
+    coarse[:, hsx // 2:] = rng.choice(np.array([0, 1, 2, 11, 12, 13, 14, 255], np.uint8), size=(hsy, hsx - hsx // 2))
+    gt = [0.0, 3.0 / W, 0.0, 3.0, 0.0, -3.0 / W]
+    sgt = [-0.01, 3.02 / hsx, 0.0, 3.01, 0.0, -3.02 / hsy]
+    ci, cj = host.build_index_maps(gt, sgt, W, H, hsx, hsy)
+    engine.set_tables(tables)
+    bufs = [engine.upload(a) for a in (esa, coarse, ci, cj)]
+    engine.prepare_tile(bufs[1].ptr, hsx, hsy, bufs[2].ptr, W)
+    out = {}
+    try:
+        for emit in (0, 1):
+            engine.set_option("arena_segment_align", seg_align)
+            engine.set_option("fused_emit", emit)
+            out[emit] = engine.deflate_fused(bufs[0].ptr, W, H, bufs[3].ptr)
+    finally:
+        engine.set_option("defaults", 0)
+        for b in bufs:
+            b.close()
+    assert out[0][2] == out[1][2], "bytes used differ: %d vs %d" % (out[0][2], out[1][2])
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][0], out[1][0])
+    table = out[1][1].reshape(18, -1, 2).astype(np.int64)
+    assert len({tuple(e) for e in table.reshape(-1, 2).tolist()}) < table.shape[0] * table.shape[1], "no aliases in this case?"
+    # every raster's own streams: one contiguous extent in tile order that starts at a multiple of the alignment
+    end_before = 0
+    for r in range(18):
+        alias = np.zeros(table.shape[1], bool)        # an alias carries an earlier raster's entry of the same position
+        for q in range(r):
+            alias |= table[q][:, 0] == table[r][:, 0]
+        own = table[r][~alias]
+        if len(own) == 0:
+            continue
+        assert own[0, 0] % seg_align == 0 and own[0, 0] >= end_before
+        slots = (own[:, 1] + 15) // 16 * 16
+        assert np.array_equal(own[1:, 0], own[0, 0] + np.cumsum(slots)[:-1])
+        end_before = own[-1, 0] + slots[-1]
+    assert end_before == out[1][2]
+
+
 def test_fused_encoder_shares_streams_where_drained_equals_undrained(engine, tables):
     """No dual soil class (11..14) under a tile: the drained and the undrained raster of a table
     are the same bytes there, and the fused encoder emits them once -- both table entries point
