@@ -586,7 +586,7 @@ __global__ __launch_bounds__(kBuildThreads) void deflate_codes_kernel(const Tile
 // parent walks, lengths by rank, canonical codes by ballots per length, the
 // code-length run-length coding by one lane per run with a prefix sum of run sizes.
 // ------------------------------------------------------------------------
-constexpr int kWavesPerBlock = 4;
+constexpr int kWavesPerBlock = 8;      // (divides 64: a workgroup's tiles lie in one chunk of the placement)
 struct WaveWork {
     uint32_t keys[256];         // (freq << 9 | symbol), sorted ascending; <= kMaxLive live
     uint16_t parent[2 * kMaxLive];
@@ -689,10 +689,35 @@ __device__ __forceinline__ uint32_t rle_run_bits(int v, int n)
 __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel(const TileJob job)
 {
     __shared__ __attribute__((aligned(16))) WaveWork work[kWavesPerBlock];
+    __shared__ uint32_t wg_bytes, wg_done;
     const int lane = threadIdx.x & 63;
-    const uint32_t tile = uni(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
-    if (tile >= job.n_tiles)
+    // a workgroup = kWavesPerBlock consecutive tiles of ONE raster (blockIdx.y): its streams' slot bytes are added up
+    // in LDS and go to the placement's chunk total (pass F-C) as one atomic per workgroup -- one per wave was 7 614
+    // device-scope atomics on 126 neighbouring words per strip, which queue up in one memory channel (+8 us)
+    if (threadIdx.x == 0) {
+        wg_bytes = 0;
+        wg_done = 0;
+    }
+    __syncthreads();
+    const uint32_t per_raster = job.across * job.down;
+    const uint32_t tile_pos = uni(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (tile_pos >= per_raster)
         return;
+    const uint32_t tile = blockIdx.y * per_raster + tile_pos;
+    const uint32_t live_waves = per_raster - blockIdx.x * kWavesPerBlock < (uint32_t)kWavesPerBlock
+                                    ? per_raster - blockIdx.x * kWavesPerBlock : (uint32_t)kWavesPerBlock;
+    auto add_up = [&](uint32_t bytes) {         // lane 0 of every wave that finishes its tile, once
+        if (!job.chunk_tot)
+            return;
+        if (bytes)
+            atomicAdd(&wg_bytes, (bytes + (uint32_t)(kSlotAlign - 1)) & ~(uint32_t)(kSlotAlign - 1));
+        // (LDS executes a wave's operations in order: whoever counts the last wave in sees every sum before it)
+        if (__hip_atomic_fetch_add(&wg_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == live_waves - 1u) {
+            const uint32_t total = __hip_atomic_load(&wg_bytes, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (total)
+                atomicAdd(&job.chunk_tot[blockIdx.y * job.n_chunks + (tile_pos >> 6)], total);
+        }
+    };
     WaveWork &w = work[threadIdx.x >> 6];
     const uint32_t *hist = job.hist + (size_t)tile * kHistWords;
     Book *book = reinterpret_cast<Book *>(job.books + (size_t)tile * kBookBytes);
@@ -704,6 +729,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
             book->slot = kAliasSlot;
             job.sizes[(size_t)tile * 2] = kAliasSlot;
             job.sizes[(size_t)tile * 2 + 1] = 0u;
+            add_up(0u);
         }
         return;
     }
@@ -1051,7 +1077,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
         book->stream_bytes = bytes;
         job.sizes[(size_t)tile * 2] = 0u;
         job.sizes[(size_t)tile * 2 + 1] = bytes;
-        add_chunk_total(job, tile, bytes);
+        add_up(bytes);
     }
 }
 
@@ -1410,7 +1436,8 @@ int deflate_launch_codes(gcn10_gpu_ctx *ctx, const TileJob &job, uint32_t nblock
 {
     static_assert(sizeof(Work) * kBuildThreads <= 160 * 1024, "code construction slices must fit LDS");
     if (ctx->deflate_wave_codes) {
-        hipLaunchKernelGGL(deflate_codes_wave_kernel, dim3((nblocks + kWavesPerBlock - 1) / kWavesPerBlock),
+        const uint32_t per_raster = job.across * job.down;
+        hipLaunchKernelGGL(deflate_codes_wave_kernel, dim3((per_raster + kWavesPerBlock - 1) / kWavesPerBlock, nblocks / per_raster),
                            dim3(64 * kWavesPerBlock), 0, s, job);
     }
     else {
