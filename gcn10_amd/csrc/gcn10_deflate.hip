@@ -823,21 +823,69 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
             uint32_t lw = (uint32_t)lane < m ? w.keys[lane] >> 9 : 0xffffffffu;
             uint32_t iw = 0xffffffffu;              // internal node k (k = 0 .. m-2), created in weight order
             uint32_t pl = 0, pn = 0;                // parent of leaf `lane`, of internal node `lane`
-            uint32_t leaf = 0, inode = 0;
-            for (uint32_t made = 0; made + 1 < m; made++) {
-                uint32_t sum = 0;
-#pragma unroll
-                for (int two = 0; two < 2; two++) {
-                    const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)lw, (int)leaf);
-                    const uint32_t wn = (uint32_t)__builtin_amdgcn_readlane((int)iw, (int)inode);
-                    const bool take_leaf = wl <= wn;        // tie: the leaf, as below
-                    sum += take_leaf ? wl : wn;
-                    pl = take_leaf && (uint32_t)lane == leaf ? m + made : pl;
-                    pn = !take_leaf && (uint32_t)lane == inode ? m + made : pn;
-                    leaf += take_leaf ? 1u : 0u;
-                    inode += take_leaf ? 0u : 1u;
-                }
-                iw = (uint32_t)lane == made ? sum : iw;
+            // Written out (the compiler keeps the queue heads in vector registers and compares them there): the two
+            // heads, the two queue positions and the sum live in scalar registers; a pick is a scalar compare and
+            // branch, one v_writelane for the parent (lane select in M0: two different SGPR operands would break the
+            // constant-bus rule) and one v_readlane for the new head of the queue it took from -- 5 vector
+            // instructions per merge (14 in the compiler's form of the loop with selects).
+            {
+                uint32_t wl, wn, leaf, inode, made, sum, par, m0_saved;
+                const uint32_t last = m - 1u;           // m >= 2 here
+                asm volatile("s_mov_b32 %[m0s], m0\n\t"
+                             "v_readlane_b32 %[wl], %[lw], 0\n\t"
+                             "s_mov_b32 %[wn], -1\n\t"
+                             "s_mov_b32 %[leaf], 0\n\t"
+                             "s_mov_b32 %[inode], 0\n\t"
+                             "s_mov_b32 %[made], 0\n"
+                             "1:\n\t"
+                             "s_add_u32 %[par], %[m], %[made]\n\t"
+                             "s_mov_b32 %[sum], 0\n\t"
+                             // first pick (tie: the leaf)
+                             "s_cmp_le_u32 %[wl], %[wn]\n\t"
+                             "s_cbranch_scc0 2f\n\t"
+                             "s_mov_b32 m0, %[leaf]\n\t"
+                             "s_add_u32 %[sum], %[sum], %[wl]\n\t"
+                             "s_add_u32 %[leaf], %[leaf], 1\n\t"
+                             "v_writelane_b32 %[pl], %[par], m0\n\t"
+                             "v_readlane_b32 %[wl], %[lw], %[leaf]\n\t"        // (lanes m .. 63: infinite)
+                             "s_branch 3f\n"
+                             "2:\n\t"
+                             "s_mov_b32 m0, %[inode]\n\t"
+                             "s_add_u32 %[sum], %[sum], %[wn]\n\t"
+                             "s_add_u32 %[inode], %[inode], 1\n\t"
+                             "v_writelane_b32 %[pn], %[par], m0\n\t"
+                             "v_readlane_b32 %[wn], %[iw], %[inode]\n"          // (not made yet: infinite)
+                             "3:\n\t"
+                             // second pick
+                             "s_cmp_le_u32 %[wl], %[wn]\n\t"
+                             "s_cbranch_scc0 4f\n\t"
+                             "s_mov_b32 m0, %[leaf]\n\t"
+                             "s_add_u32 %[sum], %[sum], %[wl]\n\t"
+                             "s_add_u32 %[leaf], %[leaf], 1\n\t"
+                             "v_writelane_b32 %[pl], %[par], m0\n\t"
+                             "v_readlane_b32 %[wl], %[lw], %[leaf]\n\t"
+                             "s_branch 5f\n"
+                             "4:\n\t"
+                             "s_mov_b32 m0, %[inode]\n\t"
+                             "s_add_u32 %[sum], %[sum], %[wn]\n\t"
+                             "s_add_u32 %[inode], %[inode], 1\n\t"
+                             "v_writelane_b32 %[pn], %[par], m0\n\t"
+                             "v_readlane_b32 %[wn], %[iw], %[inode]\n"
+                             "5:\n\t"
+                             // the new node: iw[made] = sum; it is the head of its queue if that queue was empty
+                             "s_mov_b32 m0, %[made]\n\t"
+                             "s_cmp_eq_u32 %[inode], %[made]\n\t"
+                             "s_cselect_b32 %[wn], %[sum], %[wn]\n\t"
+                             "v_writelane_b32 %[iw], %[sum], m0\n\t"
+                             "s_add_u32 %[made], %[made], 1\n\t"
+                             "s_cmp_lt_u32 %[made], %[last]\n\t"
+                             "s_cbranch_scc1 1b\n\t"
+                             "s_mov_b32 m0, %[m0s]"                              // (M0 is the compiler's: put it back)
+                             : [wl] "=&s"(wl), [wn] "=&s"(wn), [leaf] "=&s"(leaf), [inode] "=&s"(inode), [made] "=&s"(made),
+                               [sum] "=&s"(sum), [par] "=&s"(par), [m0s] "=&s"(m0_saved), [iw] "+v"(iw), [pl] "+v"(pl),
+                               [pn] "+v"(pn)
+                             : [lw] "v"(lw), [m] "s"(m), [last] "s"(last)
+                             : "scc");
             }
             if ((uint32_t)lane < m)
                 w.parent[lane] = (uint16_t)pl;
