@@ -435,6 +435,18 @@ __device__ __forceinline__ uint32_t cl_code_of(int v)
     return bitrev((uint32_t)(16 + v), 5);           // 10..15 -> 11010 .. 11111
 }
 
+// the 19 three-bit entries of the block header that describe the fixed code-length code, in kClOrder, as one number
+constexpr unsigned long long cl_len_bits()
+{
+    constexpr uint8_t order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+    constexpr uint8_t len[19] = { 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 4, 4, 4 };
+    unsigned long long v = 0;
+    for (int i = 0; i < 19; i++)
+        v |= (unsigned long long)len[order[i]] << (3 * i);
+    return v;
+}
+constexpr unsigned long long kClLenBits = cl_len_bits();       // 57 bits
+
 // serial bit writer for the block header
 struct BitWriter {
     uint32_t *out;
@@ -1015,17 +1027,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
         }
     }
     uint32_t body_bits = 0;
+    uint32_t max_len = 0;                       // (wave-uniform; a CN tile's codes seldom reach 8 bits)
+#pragma unroll
+    for (int L = 1; L <= 15; L++)
+        max_len = count[L] ? (uint32_t)L : max_len;
 #pragma unroll
     for (int c = 0; c < 5; c++) {
         const int s = c * 64 + lane;
         const uint32_t L = s < 288 ? w.len[s] : 0u;
         uint32_t code = 0;
+        if (__ballot(L != 0u) != 0ull) {        // (CN values leave whole chunks of 64 symbols unused)
 #pragma unroll
-        for (int k = 1; k <= 15; k++) {
-            const unsigned long long mask = __ballot(L == (uint32_t)k);
-            if (L == (uint32_t)k)
-                code = bitrev(next_code[k] + (uint32_t)__popcll(mask & lt_mask), k);
-            next_code[k] += (uint32_t)__popcll(mask);
+            for (int k = 1; k <= 15; k++) {
+                if ((uint32_t)k <= max_len) {
+                    const unsigned long long mask = __ballot(L == (uint32_t)k);
+                    if (L == (uint32_t)k)
+                        code = bitrev(next_code[k] + (uint32_t)__popcll(mask & lt_mask), k);
+                    next_code[k] += (uint32_t)__popcll(mask);
+                }
+            }
         }
         if (s < 288) {
             book->lit_len[s] = (uint8_t)L;
@@ -1042,8 +1062,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
     if (stop_after == 4u)
         return;                 // phase 4: + canonical codes, body size
     // ---- block header: fixed part by lane 0, the code lengths run-length coded in parallel ----
-    for (int i = lane; i < 64; i += 64)
-        w.hdr[i] = 0;
     // hlit / hdist: trailing zero lengths are not sent
     uint32_t hlit = 257;
 #pragma unroll
@@ -1058,17 +1076,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
     hlit = uni(hlit);
     const uint32_t hdist = n_far ? 16u : 1u;
     const uint32_t total = hlit + hdist;
-    wave_sync();
-    if (lane == 0) {
-        BitWriter bw{ w.hdr, 16 };
-        w.hdr[0] = 0x78u | (0x9cu << 8);        // CMF: deflate, 32K window; FLG: check bits, level 2
-        bw.put(1, 1);                           // BFINAL
-        bw.put(2, 2);                           // BTYPE = 10, dynamic Huffman
-        bw.put(hlit - 257u, 5);
-        bw.put(hdist - 1u, 5);
-        bw.put(19 - 4, 4);                      // HCLEN: all 19
-        for (int i = 0; i < 19; i++)
-            bw.put(kClLen[kClOrder[i]], 3);
+    {
+        // the fixed part in closed form (a serial bit writer on lane 0 took 24 read-modify-write trips to LDS):
+        // CMF/FLG (deflate, 32K window; check bits, level 2), BFINAL = 1, BTYPE = 10, HLIT, HDIST, HCLEN = all 19,
+        // then the 19 three-bit lengths of the fixed code-length code -- a constant
+        const unsigned long long lo = 0x9c78ull | 5ull << 16 | (unsigned long long)(hlit - 257u) << 19 |
+                                      (unsigned long long)(hdist - 1u) << 24 | 15ull << 29 | kClLenBits << 33;
+        const uint32_t hi = (uint32_t)(kClLenBits >> 31);
+        w.hdr[lane] = lane == 0 ? (uint32_t)lo : lane == 1 ? (uint32_t)(lo >> 32) : lane == 2 ? hi : 0u;
     }
     wave_sync();
     const uint32_t fixed_bits = 16 + 3 + 5 + 5 + 4 + 19 * 3;
@@ -1087,6 +1102,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
     uint32_t run_pos = fixed_bits;              // wave-uniform: bits before this chunk's runs
 #pragma unroll
     for (int c = 0; c < 5; c++) {
+        if (start_mask[c] == 0ull)
+            continue;                           // (a chunk inside one long run of zeros)
         const uint32_t i = (uint32_t)(c * 64 + lane);
         const bool start = (start_mask[c] >> lane) & 1ull;
         uint32_t run_len = 0;
