@@ -599,11 +599,11 @@ __global__ __launch_bounds__(kBuildThreads) void deflate_codes_kernel(const Tile
 // code-length run-length coding by one lane per run with a prefix sum of run sizes.
 // ------------------------------------------------------------------------
 constexpr int kWavesPerBlock = 8;      // (divides 64: a workgroup's tiles lie in one chunk of the placement)
-struct WaveWork {
+struct alignas(16) WaveWork {
     uint32_t keys[256];         // (freq << 9 | symbol), sorted ascending; <= kMaxLive live
+    uint32_t hdr[68];           // 2048 header bits at most, + the word an OR may spill into (8-byte aligned: ds_or_b64)
     uint16_t parent[2 * kMaxLive];
     uint8_t len[320];           // code length per lit/len symbol (0..285), then per distance code
-    uint32_t hdr[68];           // 2048 header bits at most, + the word an OR may spill into
 };
 
 __device__ __forceinline__ void wave_sync()
@@ -682,6 +682,37 @@ __device__ __forceinline__ uint32_t rle_run(int v, int n, uint32_t *out, uint32_
     while (left-- > 0)
         put(cl_code_of(v), vbits);
     return bits;
+}
+
+// The tokens of rle_run() for a run of `n` equal code lengths `v` as one bit string (LSB first), without loops:
+// zeros take at most 2 x 11 + 11 bits; other lengths fit 64 bits up to n = kRleStringMax (the length, at most
+// eight repeats of six, a rest of up to five).  Returns the number of bits.
+constexpr int kRleStringMax = 54;
+__device__ __forceinline__ uint32_t rle_run_string(int v, int n, unsigned long long &s)
+{
+    if (v == 0) {
+        const uint32_t q = (uint32_t)n / 138u, rem = (uint32_t)n - q * 138u;
+        const unsigned long long p11 = (unsigned long long)(cl_code_of(18) | 127u << 4);
+        s = q == 0u ? 0ull : q == 1u ? p11 : (p11 | p11 << 11);
+        const uint32_t nb = q * 11u;
+        // rest: 11..137 -> symbol 18, 3..10 -> symbol 17, 1..2 -> that many codes of length 0 (all-zero bits)
+        const unsigned long long tail = rem >= 11u ? (unsigned long long)(cl_code_of(18) | (rem - 11u) << 4)
+                                                   : rem >= 3u ? (unsigned long long)(cl_code_of(17) | (rem - 3u) << 4) : 0ull;
+        const uint32_t tb = rem >= 11u ? 11u : rem >= 3u ? 7u : rem * 4u;
+        s |= tail << nb;
+        return nb + tb;
+    }
+    const uint32_t vbits = v >= 10 && v < 16 ? 5u : 4u;
+    const unsigned long long cv = cl_code_of(v);
+    const uint32_t left = (uint32_t)n - 1u, q = left / 6u, rem = left - q * 6u;
+    // q times "repeat six" (symbol 16, extra bits 3): the six-bit pattern times ones at every sixth bit
+    const unsigned long long ones = 0x0041041041041041ull & ((1ull << (6u * q)) - 1ull);
+    const unsigned long long rep = (unsigned long long)(cl_code_of(16) | 3u << 4) * ones;
+    const unsigned long long tail = rem >= 3u ? (unsigned long long)(cl_code_of(16) | (rem - 3u) << 4)
+                                              : rem == 2u ? (cv | cv << vbits) : rem == 1u ? cv : 0ull;
+    const uint32_t tb = rem >= 3u ? 6u : rem * vbits;
+    s = cv | rep << vbits | tail << (vbits + 6u * q);
+    return vbits + 6u * q + tb;
 }
 
 // bits rle_run() spends on a run of `n` equal code lengths `v`, without walking it
@@ -1121,6 +1152,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
                         nxt = (uint32_t)(c2 * 64) + (uint32_t)__builtin_ctzll(start_mask[c2]);
             }
             run_len = nxt - i;
+        }
+        if (__ballot(start && v_at[c] != 0 && run_len > (uint32_t)kRleStringMax) == 0ull) {
+            // the usual case: every run's tokens as one string of at most 63 bits, one or two 64-bit ORs into LDS
+            unsigned long long str = 0;
+            const uint32_t bits = start ? rle_run_string(v_at[c], (int)run_len, str) : 0u;
+            const uint32_t incl = wave_scan_dpp(bits);
+            if (start) {
+                const uint32_t at = run_pos + incl - bits;
+                unsigned long long *h64 = reinterpret_cast<unsigned long long *>(w.hdr);
+                const uint32_t sh = at & 63u;
+                atomicOr(&h64[at >> 6], str << sh);
+                if (sh + bits > 64u)
+                    atomicOr(&h64[(at >> 6) + 1u], str >> (64u - sh));
+            }
+            run_pos += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            continue;
         }
         const uint32_t bits = start ? rle_run_bits(v_at[c], (int)run_len) : 0u;
         const uint32_t incl = wave_scan_dpp(bits);
