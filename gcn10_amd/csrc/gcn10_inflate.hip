@@ -944,6 +944,35 @@ __device__ __forceinline__ uint32_t decode_batch(Shared &sh, Decoder &d, uint32_
     return n;
 }
 
+// A match of 65..258 bytes whose source and destination ranges lie apart in the ring and do not cross its end
+// (offsets s_off, d_off): one dword per lane (unaligned LDS access is enabled on this platform), one byte per lane
+// for the last 0..3 bytes, ONE wait for those two reads, two writes.  copy_match()'s form of the same copy is five
+// predicated byte reads and five predicated byte writes, ~100 instructions (cycle counters, round 3: 900 cycles per
+// 258-byte match, and a patchy tile's decode waits for its copier).
+__device__ __forceinline__ void copy_long(Shared &sh, uint32_t s_off, uint32_t d_off, uint32_t len, int lane)
+{
+    const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)sh.window;
+    const uint32_t n4 = len >> 2, r = len & 3u;                 // whole dwords (16..64), bytes behind them
+    const unsigned long long m4 = n4 >= 64u ? ~0ull : (1ull << n4) - 1ull, mr = (1ull << r) - 1ull;
+    const uint32_t a4 = base + s_off + 4u * (uint32_t)lane, b4 = base + d_off + 4u * (uint32_t)lane;
+    const uint32_t a1 = base + s_off + 4u * n4 + (uint32_t)lane, b1 = base + d_off + 4u * n4 + (uint32_t)lane;
+    uint32_t v0, v1;
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "s_mov_b64 exec, %[m4]\n\t"
+                 "ds_read_b32 %[v0], %[a4]\n\t"
+                 "s_mov_b64 exec, %[mr]\n\t"
+                 "ds_read_u8 %[v1], %[a1]\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "ds_write_b8 %[b1], %[v1]\n\t"
+                 "s_mov_b64 exec, %[m4]\n\t"
+                 "ds_write_b32 %[b4], %[v0]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [v0] "=&v"(v0), [v1] "=&v"(v1), [sv] "=&s"(sv)
+                 : [a4] "v"(a4), [b4] "v"(b4), [a1] "v"(a1), [b1] "v"(b1), [m4] "s"(m4), [mr] "s"(mr)
+                 : "memory");
+}
+
 // A batch of tokens carried out one by one, in order (batches that hold a stored run).
 // Returns 0, or the reason a token cannot be carried out (a distance before the start).
 __device__ __forceinline__ uint32_t copy_batch_serial(Shared &sh, Output &o, const uint32_t *ring, uint32_t n,
@@ -997,7 +1026,7 @@ __device__ __forceinline__ uint32_t copy_batch_serial(Shared &sh, Output &o, con
 // tokens that do not read each other's output is free; C runs in stream order, and by then every
 // byte an earlier token produces is there.
 constexpr uint32_t kSubCap = kWindow / 4;     // (declared near kWindow: kSubCapBytes)
-constexpr uint32_t kShortMatch = 8;
+constexpr uint32_t kShortMatch = 64;    // stage B takes matches up to this length (sixteen dword steps + up to three bytes)
 
 __device__ __forceinline__ uint32_t copy_batch(Shared &sh, Output &o, const uint32_t *ring, uint32_t n,
                                                const uint8_t *stream, int lane, uint32_t diag = 0)
@@ -1024,7 +1053,14 @@ __device__ __forceinline__ uint32_t copy_batch(Shared &sh, Output &o, const uint
             return kErrDistance;
         const uint32_t ahead = S - off;                     // ring bytes written from dst on, once the sub-batch is out
         const bool near = dist + ahead <= (uint32_t)kWindow;
-        const bool early = is_match && l > 0u && l <= kShortMatch && near && dist >= off + l;
+        // (stage B copies with unaligned dword accesses that must stay inside the ring: neither range across its end)
+        const uint32_t s_ring = (dst - dist) & (uint32_t)kWindowMask, d_ring = dst & (uint32_t)kWindowMask;
+        const bool early = is_match && l > 0u && l <= kShortMatch && near && dist >= off + l &&
+                           s_ring + l <= (uint32_t)kWindow && d_ring + l <= (uint32_t)kWindow;
+        // ... and the longer ones of the same kind (a patchy tile is made of them: 258 bytes from the row above),
+        // one after the other but with every lane at work: stage B2
+        const bool early_long = is_match && l > kShortMatch && near && dist >= off + l &&
+                                s_ring + l <= (uint32_t)kWindow && d_ring + l <= (uint32_t)kWindow;
         // A: literals
         if (!is_match && l > 0u) {
 #pragma unroll
@@ -1032,19 +1068,115 @@ __device__ __forceinline__ uint32_t copy_batch(Shared &sh, Output &o, const uint
                 if (b < l)
                     sh.window[(dst + b) & kWindowMask] = (uint8_t)(tk >> (8u * b));
         }
-        // B: short matches that read nothing of this sub-batch
-        {
-            uint8_t v[kShortMatch];
+        // B: matches of up to kShortMatch bytes that read nothing of this sub-batch, all at once, one lane per match:
+        // up to eight dword steps (unaligned LDS access is enabled on this platform) and up to three single bytes, all
+        // the reads, ONE wait, all the writes.  Written out: the masks are scalar (ballots), the steps differ only in
+        // their immediate offsets, and the compiler would wait after every read.  Round 3: this stage took matches
+        // of at most 8 bytes, byte by byte; carried out one by one in stage C a match costs ~35 instructions of a
+        // wave that shares its SIMD's issue slots with the decoders (profiles/r03/decoder_cycle_counters.txt).
+        if (__ballot(early) != 0ull) {
+            const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)sh.window;
+            const uint32_t n4 = early ? l >> 2 : 0u, r = early ? l & 3u : 0u;
+            unsigned long long M[16], T[3];
 #pragma unroll
-            for (uint32_t b = 0; b < kShortMatch; b++)
-                v[b] = early && b < l ? sh.window[(dst - dist + b) & kWindowMask] : (uint8_t)0;
+            for (uint32_t k = 0; k < 16u; k++)
+                M[k] = __ballot(k < n4);
 #pragma unroll
-            for (uint32_t b = 0; b < kShortMatch; b++)
-                if (early && b < l)
-                    sh.window[(dst + b) & kWindowMask] = v[b];
+            for (uint32_t k = 0; k < 3u; k++)
+                T[k] = __ballot(k < r);
+            const uint32_t a = base + s_ring, b = base + d_ring, at = a + 4u * n4, bt = b + 4u * n4;
+            uint32_t v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12, v13, v14, v15, t0, t1, t2;
+            unsigned long long sv;
+            asm volatile("s_mov_b64 %[sv], exec\n\t"
+                         "s_mov_b64 exec, %[M0]\n\t"
+                         "ds_read_b32 %[v0], %[a]\n\t"
+                         "s_mov_b64 exec, %[M1]\n\t"
+                         "ds_read_b32 %[v1], %[a] offset:4\n\t"
+                         "s_mov_b64 exec, %[M2]\n\t"
+                         "ds_read_b32 %[v2], %[a] offset:8\n\t"
+                         "s_mov_b64 exec, %[M3]\n\t"
+                         "ds_read_b32 %[v3], %[a] offset:12\n\t"
+                         "s_mov_b64 exec, %[M4]\n\t"
+                         "ds_read_b32 %[v4], %[a] offset:16\n\t"
+                         "s_mov_b64 exec, %[M5]\n\t"
+                         "ds_read_b32 %[v5], %[a] offset:20\n\t"
+                         "s_mov_b64 exec, %[M6]\n\t"
+                         "ds_read_b32 %[v6], %[a] offset:24\n\t"
+                         "s_mov_b64 exec, %[M7]\n\t"
+                         "ds_read_b32 %[v7], %[a] offset:28\n\t"
+                         "s_mov_b64 exec, %[M8]\n\t"
+                         "ds_read_b32 %[v8], %[a] offset:32\n\t"
+                         "s_mov_b64 exec, %[M9]\n\t"
+                         "ds_read_b32 %[v9], %[a] offset:36\n\t"
+                         "s_mov_b64 exec, %[M10]\n\t"
+                         "ds_read_b32 %[v10], %[a] offset:40\n\t"
+                         "s_mov_b64 exec, %[M11]\n\t"
+                         "ds_read_b32 %[v11], %[a] offset:44\n\t"
+                         "s_mov_b64 exec, %[M12]\n\t"
+                         "ds_read_b32 %[v12], %[a] offset:48\n\t"
+                         "s_mov_b64 exec, %[M13]\n\t"
+                         "ds_read_b32 %[v13], %[a] offset:52\n\t"
+                         "s_mov_b64 exec, %[M14]\n\t"
+                         "ds_read_b32 %[v14], %[a] offset:56\n\t"
+                         "s_mov_b64 exec, %[M15]\n\t"
+                         "ds_read_b32 %[v15], %[a] offset:60\n\t"
+                         "s_mov_b64 exec, %[T0]\n\t"
+                         "ds_read_u8 %[t0], %[at]\n\t"
+                         "s_mov_b64 exec, %[T1]\n\t"
+                         "ds_read_u8 %[t1], %[at] offset:1\n\t"
+                         "s_mov_b64 exec, %[T2]\n\t"
+                         "ds_read_u8 %[t2], %[at] offset:2\n\t"
+                         "s_waitcnt lgkmcnt(0)\n\t"
+                         "ds_write_b8 %[bt], %[t2] offset:2\n\t"
+                         "s_mov_b64 exec, %[T1]\n\t"
+                         "ds_write_b8 %[bt], %[t1] offset:1\n\t"
+                         "s_mov_b64 exec, %[T0]\n\t"
+                         "ds_write_b8 %[bt], %[t0]\n\t"
+                         "s_mov_b64 exec, %[M15]\n\t"
+                         "ds_write_b32 %[b], %[v15] offset:60\n\t"
+                         "s_mov_b64 exec, %[M14]\n\t"
+                         "ds_write_b32 %[b], %[v14] offset:56\n\t"
+                         "s_mov_b64 exec, %[M13]\n\t"
+                         "ds_write_b32 %[b], %[v13] offset:52\n\t"
+                         "s_mov_b64 exec, %[M12]\n\t"
+                         "ds_write_b32 %[b], %[v12] offset:48\n\t"
+                         "s_mov_b64 exec, %[M11]\n\t"
+                         "ds_write_b32 %[b], %[v11] offset:44\n\t"
+                         "s_mov_b64 exec, %[M10]\n\t"
+                         "ds_write_b32 %[b], %[v10] offset:40\n\t"
+                         "s_mov_b64 exec, %[M9]\n\t"
+                         "ds_write_b32 %[b], %[v9] offset:36\n\t"
+                         "s_mov_b64 exec, %[M8]\n\t"
+                         "ds_write_b32 %[b], %[v8] offset:32\n\t"
+                         "s_mov_b64 exec, %[M7]\n\t"
+                         "ds_write_b32 %[b], %[v7] offset:28\n\t"
+                         "s_mov_b64 exec, %[M6]\n\t"
+                         "ds_write_b32 %[b], %[v6] offset:24\n\t"
+                         "s_mov_b64 exec, %[M5]\n\t"
+                         "ds_write_b32 %[b], %[v5] offset:20\n\t"
+                         "s_mov_b64 exec, %[M4]\n\t"
+                         "ds_write_b32 %[b], %[v4] offset:16\n\t"
+                         "s_mov_b64 exec, %[M3]\n\t"
+                         "ds_write_b32 %[b], %[v3] offset:12\n\t"
+                         "s_mov_b64 exec, %[M2]\n\t"
+                         "ds_write_b32 %[b], %[v2] offset:8\n\t"
+                         "s_mov_b64 exec, %[M1]\n\t"
+                         "ds_write_b32 %[b], %[v1] offset:4\n\t"
+                         "s_mov_b64 exec, %[M0]\n\t"
+                         "ds_write_b32 %[b], %[v0]\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2), [v3] "=&v"(v3), [v4] "=&v"(v4), [v5] "=&v"(v5), [v6] "=&v"(v6), [v7] "=&v"(v7), [v8] "=&v"(v8), [v9] "=&v"(v9), [v10] "=&v"(v10), [v11] "=&v"(v11), [v12] "=&v"(v12), [v13] "=&v"(v13), [v14] "=&v"(v14), [v15] "=&v"(v15), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [sv] "=&s"(sv)
+                         : [a] "v"(a), [b] "v"(b), [at] "v"(at), [bt] "v"(bt), [M0] "s"(M[0]), [M1] "s"(M[1]), [M2] "s"(M[2]), [M3] "s"(M[3]), [M4] "s"(M[4]), [M5] "s"(M[5]), [M6] "s"(M[6]), [M7] "s"(M[7]), [M8] "s"(M[8]), [M9] "s"(M[9]), [M10] "s"(M[10]), [M11] "s"(M[11]), [M12] "s"(M[12]), [M13] "s"(M[13]), [M14] "s"(M[14]), [M15] "s"(M[15]), [T0] "s"(T[0]), [T1] "s"(T[1]), [T2] "s"(T[2])
+                         : "memory");
+        }
+        // B2: long matches that read nothing of this sub-batch
+        for (unsigned long long todo = __ballot(early_long); todo != 0ull; todo &= todo - 1ull) {
+            const int i = __builtin_ctzll(todo);
+            copy_long(sh, (uint32_t)__builtin_amdgcn_readlane((int)s_ring, i), (uint32_t)__builtin_amdgcn_readlane((int)d_ring, i),
+                      (uint32_t)__builtin_amdgcn_readlane((int)l, i), lane);
         }
         // C: the other matches, in order
-        unsigned long long rest = __ballot(is_match && l > 0u && !early);
+        unsigned long long rest = __ballot(is_match && l > 0u && !early && !early_long);
         if (diag == 3u)
             rest = 0ull;                // (timing: without the matches carried out one by one)
         const uint32_t pos0 = o.pos;

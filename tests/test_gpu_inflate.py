@@ -210,6 +210,106 @@ def test_full_size_tiles_of_a_block_row(engine):
         assert np.array_equal(out[:, 1024 * k:1024 * (k + 1)].reshape(-1), tiles[k]), k
 
 
+class _FixedWriter:
+    """A zlib stream of ONE fixed-Huffman block (RFC 1951 3.2.6) from an explicit token list, so that a test
+    decides every match's length and distance itself (zlib's own parser would not)."""
+    _LBASE = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
+    _LEXTRA = [0] * 8 + [1] * 4 + [2] * 4 + [3] * 4 + [4] * 4 + [5] * 4 + [0]
+    _DBASE = [1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097,
+              6145, 8193, 12289, 16385, 24577]
+    _DEXTRA = [0, 0, 0, 0] + [k for k in range(1, 14) for _ in (0, 1)]
+
+    def __init__(self):
+        self.acc, self.n, self.out, self.raw = 0, 0, bytearray(b"\x78\x01"), bytearray()
+        self._bits(1, 1)        # BFINAL
+        self._bits(1, 2)        # BTYPE = 01
+
+    def _bits(self, v, n):          # LSB first
+        self.acc |= v << self.n
+        self.n += n
+        while self.n >= 8:
+            self.out.append(self.acc & 0xff)
+            self.acc >>= 8
+            self.n -= 8
+
+    def _code(self, code, n):       # Huffman codes go in MSB first
+        self._bits(int(format(code, "0%db" % n)[::-1], 2), n)
+
+    def _litlen(self, sym):
+        if sym < 144:
+            self._code(0x30 + sym, 8)
+        elif sym < 256:
+            self._code(0x190 + sym - 144, 9)
+        elif sym < 280:
+            self._code(sym - 256, 7)
+        else:
+            self._code(0xc0 + sym - 280, 8)
+
+    def literal(self, b):
+        self._litlen(b)
+        self.raw.append(b)
+
+    def match(self, length, dist):
+        assert 3 <= length <= 258 and 1 <= dist <= len(self.raw) and dist <= 32768
+        k = max(i for i, b in enumerate(self._LBASE) if b <= length) if length < 258 else 28
+        self._litlen(257 + k)
+        self._bits(length - self._LBASE[k], self._LEXTRA[k])
+        d = max(i for i, b in enumerate(self._DBASE) if b <= dist)
+        self._code(d, 5)
+        self._bits(dist - self._DBASE[d], self._DEXTRA[d])
+        for _ in range(length):
+            self.raw.append(self.raw[-dist])
+
+    def finish(self):
+        self._litlen(256)
+        if self.n:
+            self._bits(0, 8 - self.n)
+        return bytes(self.out) + zlib.adler32(bytes(self.raw)).to_bytes(4, "big"), bytes(self.raw)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_matches_of_every_length_from_far_and_near_sources(engine, seed):
+    """Round 3: the copier carries out, all at once, every match of up to 64 bytes whose source lies before the
+    batch at hand (dword steps + tail bytes, inside the 8 KiB ring), longer such matches one by one with every lane
+    at work, and the others in order.  A hand-made token stream drives each kind through the ring many times: every
+    length 3..258, distances from just behind the batch to the far end of the ring and beyond it (sources already
+    flushed to HBM), sources that end exactly where the batch starts, matches that read the match before them,
+    short-period repeats, single literals in between."""
+    rng = np.random.default_rng(seed)
+    w = _FixedWriter()
+    for _ in range(9000):
+        w.literal(int(rng.integers(0, 256)))
+    lengths = list(range(3, 259)) * 3
+    rng.shuffle(lengths)
+    for k, length in enumerate(lengths):
+        have = len(w.raw)
+        kind = k % 8
+        if kind == 0:
+            dist = int(rng.integers(length, 200))               # near: may read tokens of the same batch
+        elif kind == 1:
+            dist = int(rng.integers(2500, 7000))                # before the batch, inside the ring
+        elif kind == 2:
+            dist = int(rng.integers(8100, min(have, 32768)))    # beyond the ring: read back from HBM
+        elif kind == 3:
+            dist = int(rng.integers(1, max(2, min(length, 64))))   # reads its own output
+        elif kind == 4:
+            dist = length                                       # source ends where the match starts
+        elif kind == 5:
+            dist = int(rng.integers(7600, 8200))                # around the ring's size
+        elif kind == 6:
+            dist = 1024                                         # the row above of a 1024-px tile
+        else:
+            dist = int(rng.integers(length, 2200))              # around the sub-batch limit
+        w.match(length, min(dist, have))
+        if k % 5 == 0:
+            w.literal(int(rng.integers(0, 256)))
+    stream, raw = w.finish()
+    assert zlib.decompress(stream) == raw
+    out, status = _one(engine, stream, len(raw))
+    assert status == 0
+    assert out.tobytes() == raw
+
+
 def _zlib_result(stream, n):
     d = zlib.decompressobj()
     try:
