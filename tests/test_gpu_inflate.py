@@ -285,7 +285,7 @@ def test_matches_of_every_length_from_far_and_near_sources(engine, seed):
         have = len(w.raw)
         kind = k % 8
         if kind == 0:
-            dist = int(rng.integers(length, 200))               # near: may read tokens of the same batch
+            dist = int(rng.integers(length, length + 200))      # near: may read tokens of the same batch
         elif kind == 1:
             dist = int(rng.integers(2500, 7000))                # before the batch, inside the ring
         elif kind == 2:
@@ -299,7 +299,7 @@ def test_matches_of_every_length_from_far_and_near_sources(engine, seed):
         elif kind == 6:
             dist = 1024                                         # the row above of a 1024-px tile
         else:
-            dist = int(rng.integers(length, 2200))              # around the sub-batch limit
+            dist = int(rng.integers(length, length + 2200))     # around the sub-batch limit
         w.match(length, min(dist, have))
         if k % 5 == 0:
             w.literal(int(rng.integers(0, 256)))
