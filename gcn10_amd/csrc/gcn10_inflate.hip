@@ -493,6 +493,19 @@ __device__ __forceinline__ void copy_match(Shared &sh, Output &o, uint32_t len, 
                 sh.window[(o.pos + k) & kWindowMask] = sh.window[(from + k) & kWindowMask];
         }
     }
+    else if (dist == 1u && len >= 16u && (o.pos & (uint32_t)kWindowMask) + len <= (uint32_t)kWindow) {
+        // a long run of one byte (every constant stretch of a landcover row is one), not across the ring's end: the
+        // byte four times in a dword, one dword per lane and up to three bytes behind them.  (Runs of a few bytes,
+        // which i.i.d. pixels are full of, stay with the general form below: it is faster for them.)
+        const uint32_t d_off = o.pos & (uint32_t)kWindowMask;
+        const uint32_t v = (uint32_t)sh.window[from & kWindowMask] * 0x01010101u;
+        const uint32_t n4 = len >> 2, r = len & 3u;
+        typedef uint32_t u32_u __attribute__((aligned(1)));
+        if ((uint32_t)lane < n4)
+            *reinterpret_cast<u32_u *>(sh.window + d_off + 4u * (uint32_t)lane) = v;
+        if ((uint32_t)lane < r)
+            sh.window[d_off + 4u * n4 + (uint32_t)lane] = (uint8_t)v;
+    }
     else {
         // the copy repeats the last `dist` bytes: lane l always writes pattern byte l mod dist
         // when the step is a multiple of dist
