@@ -710,16 +710,9 @@ __global__ __launch_bounds__(kFA2Threads, 8) void fused_stats_seg_kernel(const F
     // statistics of the final parse
     const unsigned long long lits = ~covered;
     const uint32_t my_tokens = (uint32_t)__popcll(lits) + (uint32_t)__popcll(starts);
-    for (unsigned long long m = starts; m; m &= m - 1ull) {
-        const int p = __builtin_ctzll(m);
-        const bool far = ((fars >> p) & 1ull) != 0;
-        atomicAdd(&sh.a.lit_hist[257 + length_code(ext_run(far, p))], 1u);
-        atomicAdd(&sh.a.dist_hist[far ? 1 : 0], 1u);
-    }
-    if (!(job.diag & 8u))
-        for (unsigned long long m = lits; m; m &= m - 1ull)
-            atomicAdd(&sh.a.lit_hist[rowp[seg * kSegPx + __builtin_ctzll(m)]], 1u);
-    __syncthreads();            // (the leads are read above; seg_at below shares their memory with nothing, but the scan needs all counts)
+    // (the statistics of the tokens -- literals by class, match length symbols, the two distances -- are counted where
+    // the tokens are written out, below: one walk over a segment's literals and one over its matches instead of two
+    // each; the scan in between needs the counts of tokens only)
 
     // raster order = (row, seg): an exclusive prefix over the 1024 counts says where each segment's tokens go
     sh.a.seg_at[row * kSegs + seg] = my_tokens;
@@ -746,21 +739,43 @@ __global__ __launch_bounds__(kFA2Threads, 8) void fused_stats_seg_kernel(const F
         uint32_t at = sh.a.seg_at[row * kSegs + seg];
         uint16_t *out = job.tok + (size_t)tix * kTokStride;
         if (!(job.diag & 16u)) {
-            for (unsigned long long m = lits | starts; m; m &= m - 1ull) {
+            // Literals and matches in loops of their own (a token's place is its rank among the segment's token
+            // starts): in one loop over all tokens a wave executed both paths in every trip, as often as its busiest
+            // lane has tokens -- 18 of the kernel's 76 us on noisy tiles.  (Neither the LDS round trip per token nor
+            // the scattered 2-byte stores were what that cost: reading ahead, or writing the tokens side by side,
+            // changed nothing.)
+            const unsigned long long all = lits | starts;
+            for (unsigned long long m = lits; m; m &= m - 1ull) {
                 const int p = __builtin_ctzll(m);
-                if ((lits >> p) & 1ull) {
-                    out[at++] = (uint16_t)rowp[seg * kSegPx + p];
-                }
-                else {
-                    const bool far = ((fars >> p) & 1ull) != 0;
-                    const int len = ext_run(far, p);
-                    const int lc = length_code(len);
-                    out[at++] = (uint16_t)(kTokMatch | (uint32_t)lc | (uint32_t)(len - (lc == 28 ? 258 : kLenBase[lc])) << 5 |
-                                           (far ? 1u : 0u) << 10);
-                }
+                const uint32_t c = rowp[seg * kSegPx + p];
+                if (!(job.diag & 8u))
+                    atomicAdd(&sh.a.lit_hist[c], 1u);
+                out[at + (uint32_t)__popcll(all & ((1ull << p) - 1ull))] = (uint16_t)c;
             }
+            for (unsigned long long m = starts; m; m &= m - 1ull) {
+                const int p = __builtin_ctzll(m);
+                const bool far = ((fars >> p) & 1ull) != 0;
+                const int len = ext_run(far, p);
+                uint32_t ev;                    // (no table: a global load per match inside this divergent loop)
+                const int lc = length_code_extra(len, ev);
+                atomicAdd(&sh.a.lit_hist[257 + lc], 1u);
+                atomicAdd(&sh.a.dist_hist[far ? 1 : 0], 1u);
+                out[at + (uint32_t)__popcll(all & ((1ull << p) - 1ull))] =
+                    (uint16_t)(kTokMatch | (uint32_t)lc | ev << 5 | (far ? 1u : 0u) << 10);
+            }
+            at += my_tokens;
         }
         else {
+            // (timing: without the token write-out; the statistics all the same)
+            for (unsigned long long m = starts; m; m &= m - 1ull) {
+                const int p = __builtin_ctzll(m);
+                const bool far = ((fars >> p) & 1ull) != 0;
+                atomicAdd(&sh.a.lit_hist[257 + length_code(ext_run(far, p))], 1u);
+                atomicAdd(&sh.a.dist_hist[far ? 1 : 0], 1u);
+            }
+            if (!(job.diag & 8u))
+                for (unsigned long long m = lits; m; m &= m - 1ull)
+                    atomicAdd(&sh.a.lit_hist[rowp[seg * kSegPx + __builtin_ctzll(m)]], 1u);
             at += my_tokens;
         }
         if (t == kFA2Threads - 1) {

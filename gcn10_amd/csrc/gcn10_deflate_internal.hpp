@@ -55,6 +55,21 @@ __device__ __forceinline__ int length_code(int len)
     return 4 * eb + 4 + ((l >> eb) & 3);
 }
 
+// length_code() and the value of the code's extra bits (len - kLenBase[code]) without the table: for len > 10,
+// len - 3 = (4 + q) << eb | extra with q = two bits, so the extra bits are the low eb bits of len - 3
+__device__ __forceinline__ int length_code_extra(int len, uint32_t &extra)
+{
+    extra = 0;
+    if (len == 258)
+        return 28;
+    if (len <= 10)
+        return len - 3;
+    const int l = len - 3;
+    const int eb = 29 - __builtin_clz(l);
+    extra = (uint32_t)l & ((1u << eb) - 1u);
+    return 4 * eb + 4 + ((l >> eb) & 3);
+}
+
 struct TileJob {
     const uint8_t *const *rasters;      // device array of raster strip pointers
     uint8_t *arena;
