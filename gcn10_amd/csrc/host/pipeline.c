@@ -1079,12 +1079,14 @@ int gcn10_run(const gcn10_run_options *opt)
         if ((r->cond_mask >> (k / 9)) & 1u && (r->table_mask >> (k % 9)) & 1u)
             r->sel[r->n_sel++] = k;
     r->null_sink = sink && strcmp(sink, "null") == 0;
-    /* 768 rows: three tile rows of a 36000-px block are 423 tile positions, one round of the fused
-     * statistics pass's 512 workgroup slots (1024 rows: 564 positions, a full round and a ragged one).
-     * Round 2, 16 blocks, null sink: 0.0267 vs 0.0277-0.0297 s per block on patchy tiles, 0.0557 vs
-     * 0.0564-0.0573 on noisy ones (profiles/r02/strip_rows_ab.txt); 512 and 1280 are no better, and 1792
-     * (whole rounds again, 16-19 % faster per row at kernel level) loses end to end to the coarser
-     * hand-over between kernels, copy-back and file writes */
+    /* Rows per strip.  Rounds 2 and 3 ran 768 rows (three tile rows of a 36000-px block = 423 tile positions, one round
+     * of the fused statistics pass's 512 workgroup slots); larger strips lost end to end to the coarser hand-over between
+     * kernels, copy-back and file writes (profiles/r02/strip_rows_ab.txt, profiles/r03/pipeline_strip_rows_48_blocks.txt).
+     * With the kernels of the end of round 3 a 768-row strip is 0.11-0.22 ms of GPU work, and what a strip costs
+     * besides -- a dozen HIP calls, three launch prologues, 18 writes -- weighs more: 2304 rows (nine tile rows),
+     * 72 blocks, steady state, patchy blocks: null sink 0.0074 -> 0.0063 s per block, files 0.0107 -> 0.0092;
+     * noisy blocks unchanged within the noise (profiles/r03/sink_sweep2_patches_72_blocks.txt,
+     * strip_rows3_natural_72_blocks.txt).  3072 is no better; pinned memory grows with the strip (1.9 GB per GPU). */
     r->strip_rows = r->cfg.strip_rows > 0 ? (r->cfg.strip_rows + TILE - 1) / TILE * TILE : DEFAULT_STRIP_ROWS;
     if (r->strip_rows > MAX_STRIP_ROWS)     /* a strip's compressed-tile arena must stay below 4 GiB (32-bit offsets) */
         r->strip_rows = MAX_STRIP_ROWS;

@@ -12,7 +12,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-enum { TILE = 256, MAX_NBUF = 8, DEFAULT_NBUF = 4, DEFAULT_STRIP_ROWS = 768, MAX_STRIP_ROWS = 4096 };
+enum { TILE = 256, MAX_NBUF = 8, DEFAULT_NBUF = 4, DEFAULT_STRIP_ROWS = 2304, MAX_STRIP_ROWS = 4096 };
 
 struct run;
 
