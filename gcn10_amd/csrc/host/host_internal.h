@@ -20,6 +20,8 @@ typedef void (*gcn10_job_fn)(void *arg);
 gcn10_pool *gcn10_pool_create(int n_threads);
 void gcn10_pool_submit(gcn10_pool *p, gcn10_job_fn fn, void *arg);
 void gcn10_pool_destroy(gcn10_pool *p);     /* drains the queue first */
+double gcn10_pool_cpu_seconds(gcn10_pool *p);   /* CPU time its (live) threads have used so far */
+double gcn10_thread_cpu_seconds(void);          /* ... the calling thread */
 
 /* Like gcn10_tiff_read_window / gcn10_raster_read, with the tiles or strips of the
  * window decoded concurrently on `pool` (NULL = on the calling thread). */

@@ -939,6 +939,7 @@ static void *worker_main(void *arg)
             break;
     }
     worker_teardown(w);
+    w->cpu_seconds = gcn10_thread_cpu_seconds();
     return NULL;
 }
 
@@ -1372,6 +1373,19 @@ int gcn10_run(const gcn10_run_options *opt)
                          done_blocks > 0 ? cpu / done_blocks : 0.0, ru.ru_nvcsw, ru.ru_nivcsw,
                          (double)atomic_load(&r->pinned_bytes) / 1e6, (double)ru.ru_maxrss / 1e3);
                 gcn10_log_message(log0, "INFO", msg, false);
+                {
+                    /* ... by kind of thread; the rest is the HIP runtime's own threads and the main thread */
+                    double enc = 0.0, inp = 0.0;
+                    const double io = gcn10_pool_cpu_seconds(r->pool);
+
+                    for (int i = 0; i < r->n_workers; i++) {
+                        enc += r->workers[i].cpu_seconds;
+                        inp += r->workers[i].in_cpu_seconds;
+                    }
+                    snprintf(msg, sizeof msg, "timing: host cpu seconds by thread: encoder workers %.3f, input threads %.3f, "
+                             "i/o pool %.3f, others (HIP runtime, main) %.3f", enc, inp, io, cpu - enc - inp - io);
+                    gcn10_log_message(log0, "INFO", msg, false);
+                }
             }
         }
         /* one line per GPU: when a node's GPUs are not equally busy, these tell a slow device or PCIe

@@ -472,7 +472,7 @@ static void *input_main(void *arg)
             pthread_cond_wait(&w->in_cv, &w->in_mu);
         if (w->in_stop) {
             pthread_mutex_unlock(&w->in_mu);
-            return NULL;
+            { w->in_cpu_seconds = gcn10_thread_cpu_seconds(); return NULL; }
         }
         in->state = IN_FILLING;
         pthread_mutex_unlock(&w->in_mu);
@@ -484,7 +484,7 @@ static void *input_main(void *arg)
         pthread_cond_broadcast(&w->in_cv);
         pthread_mutex_unlock(&w->in_mu);
         if (!more)
-            return NULL;
+            { w->in_cpu_seconds = gcn10_thread_cpu_seconds(); return NULL; }
     }
 }
 

@@ -111,6 +111,7 @@ struct worker {
     int numa_node;                          /* ... and the NUMA node it hangs off (-1 = unknown) */
     char pci_bus[64];
     double busy_seconds;
+    double cpu_seconds, in_cpu_seconds;        /* CPU time of the worker's thread and of its input thread */
     double t_first_block;                   /* when this worker started its first block */
     double t_first_done, t_last_done;       /* when it finished its first / its last block */
     double t_gpu_wait, t_sink_wait;         /* where the worker thread's time goes */

@@ -9,6 +9,7 @@
 #include "host_internal.h"
 
 #include <pthread.h>
+#include <time.h>
 #include <stdlib.h>
 
 struct job {
@@ -48,6 +49,27 @@ static void *pool_main(void *arg)
         j->fn(j->arg);
         free(j);
     }
+}
+
+double gcn10_thread_cpu_seconds(void)
+{
+    struct timespec ts;
+
+    return clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) == 0 ? (double)ts.tv_sec + ts.tv_nsec * 1e-9 : 0.0;
+}
+
+double gcn10_pool_cpu_seconds(gcn10_pool *p)
+{
+    double sum = 0.0;
+
+    for (int i = 0; p && i < p->n; i++) {
+        clockid_t cid;
+        struct timespec ts;
+
+        if (pthread_getcpuclockid(p->threads[i], &cid) == 0 && clock_gettime(cid, &ts) == 0)
+            sum += (double)ts.tv_sec + ts.tv_nsec * 1e-9;
+    }
+    return sum;
 }
 
 gcn10_pool *gcn10_pool_create(int n_threads)

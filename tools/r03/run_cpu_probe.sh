@@ -5,12 +5,16 @@ R=$GRAFT_REPO_ROOT
 W=/tmp/gcn10_c
 python3 $R/tools/bench_pipeline.py --pattern patches --blocks 8 --repeat 9 --modes null --keep --esa-compression 8 --workdir $W > /dev/null 2>&1
 cd $W
-for io in 0 4 8 16; do
+for io in 0; do
   sed -i "s/^io_threads=.*/io_threads=$io/" config.txt
   rm -rf logs cn_rasters_drained cn_rasters_undrained
-  $R/bin/gcn10 -c config.txt -o --gpus 1 > /dev/null 2>&1
-  echo "io_threads=$io"
-  grep -h "timing\|host cpu" logs/rank_0.log | sed 's/^[^]]*\] //' | cut -c1-420
+  for sink in files null; do
+    rm -rf logs cn_rasters_drained cn_rasters_undrained
+    if [ $sink = null ]; then export GCN10_SINK=null; else unset GCN10_SINK; fi
+    $R/bin/gcn10 -c config.txt -o --gpus 1 > /dev/null 2>&1
+    echo "io_threads=$io sink=$sink"
+    grep -h "timing: steady\|host cpu" logs/rank_0.log | sed 's/^[^]]*\] //' | cut -c1-420
+  done
 done
 which strace perf ltrace 2>/dev/null
 rm -rf $W
