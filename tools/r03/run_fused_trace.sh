@@ -9,7 +9,7 @@ cd /tmp
 for v in head $VARIANTS; do
   if [ $v = head ]; then unset GCN10_GPU_LIB; else export GCN10_GPU_LIB=$R/variants/$v/libgcn10_gpu.so; fi
   for pat in natural patches; do
-    rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$pat -- python3 $R/tools/bench_fused.py --pattern $pat --rows 768 --diags 0 --reps 9 > $O/kt_$pat.log 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$pat -- python3 $R/tools/bench_fused.py --pattern $pat --rows ${ROWS:-768} --diags 0 --reps 9 > $O/kt_$pat.log 2>&1
     cp $(ls -t $O/kt_$pat/*/*kernel_stats.csv | head -1) $O/kernel_stats_fused_${v}_$pat.csv
     rm -rf $O/kt_$pat
   done
