@@ -46,7 +46,16 @@ const char *gcn10_gpu_library_path(void)
 
 static void load_once(void)
 {
-    void *h = dlopen(gcn10_gpu_library_path(), RTLD_NOW | RTLD_LOCAL);
+    void *h;
+
+    /* Hardware queues of this process on a device: the ROCm runtime maps its streams onto 4 by default, and streams
+     * that share one run in order.  With two workers per GPU the program has six busy streams (kernels, copy-back
+     * and input of each worker): on 4 queues the two workers' kernel streams landed on the same one
+     * (profiles/r03/pipeline_kernel_overlap_*: "by (queue, stream)").  16 queues, 72 blocks, steady state: noisy
+     * blocks 0.0183 -> 0.0164 s, patchy ones with files 0.0089 -> 0.0080 (profiles/r03/hw_queues_72_blocks.txt).
+     * Set before the HIP runtime is loaded; a value the user has set stays. */
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    h = dlopen(gcn10_gpu_library_path(), RTLD_NOW | RTLD_LOCAL);
 
     if (!h)
         h = dlopen("libgcn10_gpu.so", RTLD_NOW | RTLD_LOCAL);
