@@ -1,4 +1,4 @@
-R=$GRAFT_REPO_ROOT
+R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/r03_pipeline
 for pat in patches natural; do
   python3 $R/tools/bench_pipeline.py --pattern $pat --blocks 8 --repeat 9 --modes null --keep --esa-compression 8 --workdir /tmp/gcn10_w3_$pat > /dev/null 2>&1
   for rep in 1 2; do for wk in 2 3 4; do
