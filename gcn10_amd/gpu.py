@@ -365,12 +365,13 @@ class Engine:
         return data, tab, used
 
     def deflate_fused(self, esa_d: int, W: int, rows: int, cj_d: int, cond_mask: int = 3,
-                      table_mask: int = ALL_TABLES, stream=None):
+                      table_mask: int = ALL_TABLES, stream=None, arena_cap: Optional[int] = None):
         """Encoded tiles of the selected rasters straight from landcover + prepared soil
-        (gcn10_gpu_deflate_fused_strip).  Returns (arena bytes, table uint32[n, down, across, 2], used)."""
+        (gcn10_gpu_deflate_fused_strip).  Returns (arena bytes, table uint32[n, down, across, 2], used).
+        arena_cap: an arena smaller than gcn10_gpu_deflate_arena_bound (tests: streams that do not fit)."""
         n = bin(cond_mask & 3).count("1") * bin(table_mask & ALL_TABLES).count("1")
         across, down = (W + 255) // 256, (rows + 255) // 256
-        cap = int(lib().gcn10_gpu_deflate_arena_bound(W, rows, n))
+        cap = int(lib().gcn10_gpu_deflate_arena_bound(W, rows, n)) if arena_cap is None else int(arena_cap)
         arena = self.alloc(cap)
         table = self.alloc(n * across * down * 8)
         cursor = self.alloc(8)

@@ -295,6 +295,43 @@ def test_streams_placed_by_the_bit_packing_pass_lie_where_the_placement_pass_put
     assert end_before == out[1][2]
 
 
+@pytest.mark.parametrize("emit", [0, 1])
+def test_an_arena_too_small_for_the_strip_says_so_and_keeps_what_fits(engine, tables, emit):
+    """include/gcn10_gpu.h: a stream that does not fit the caller's arena gets offset 0xffffffff and size 0, the
+    bytes used are reported in full (the host sees used > capacity and gives the strip up), and nothing is written
+    behind the arena's end.  Both placements: pass B' and the one inside pass F-C."""
+    import bench
+    from gcn10_amd import host
+    H, W = 512, 1024 + 60
+    rng = np.random.default_rng(5)
+    esa = np.ascontiguousarray(bench.synth_block(6, 2048, "natural")[0][:H, :W])
+    hsy, hsx = H // 25 + 2, W // 25 + 2
+    coarse = rng.choice(np.array([0, 1, 2, 3, 4, 11, 12, 13, 14, 255], np.uint8), size=(hsy, hsx))
+    gt = [0.0, 3.0 / W, 0.0, 3.0, 0.0, -3.0 / W]
+    sgt = [0.0, 3.0 / hsx, 0.0, 3.0, 0.0, -3.0 / hsy]
+    ci, cj = host.build_index_maps(gt, sgt, W, H, hsx, hsy)
+    engine.set_tables(tables)
+    bufs = [engine.upload(a) for a in (esa, coarse, ci, cj)]
+    engine.prepare_tile(bufs[1].ptr, hsx, hsy, bufs[2].ptr, W)
+    try:
+        engine.set_option("fused_emit", emit)
+        full_data, full_tab, full_used = engine.deflate_fused(bufs[0].ptr, W, H, bufs[3].ptr)
+        cap = (full_used * 3 // 5) // 4096 * 4096
+        data, tab, used = engine.deflate_fused(bufs[0].ptr, W, H, bufs[3].ptr, arena_cap=cap)
+    finally:
+        engine.set_option("defaults", 0)
+        for b in bufs:
+            b.close()
+    assert used == full_used and used > cap
+    full_tab, tab = full_tab.reshape(-1, 2), tab.reshape(-1, 2)
+    fits = full_tab[:, 0].astype(np.int64) + (full_tab[:, 1].astype(np.int64) + 15) // 16 * 16 <= cap
+    assert fits.any() and (~fits).any()
+    assert np.array_equal(tab[fits], full_tab[fits])
+    assert (tab[~fits, 0] == 0xffffffff).all() and (tab[~fits, 1] == 0).all()
+    for off, size in tab[fits]:
+        assert np.array_equal(data[off:off + size], full_data[off:off + size])
+
+
 def test_fused_encoder_shares_streams_where_drained_equals_undrained(engine, tables):
     """No dual soil class (11..14) under a tile: the drained and the undrained raster of a table
     are the same bytes there, and the fused encoder emits them once -- both table entries point
