@@ -831,6 +831,21 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
         count[1] = 1;
     }
     else {
+        if (m <= 63u) {
+            // ---- the usual case: every lane ranks its own key among the m (keys are distinct: the symbol is in
+            // them) with one v_readlane and a compare per key, and puts it where it belongs -- ~3 m instructions
+            // instead of the 21 compare-exchange passes through LDS of the network below ----
+            wave_sync();
+            const uint32_t key = (uint32_t)lane < m ? w.keys[lane] : 0xffffffffu;
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < m; j++)
+                rank += (uint32_t)__builtin_amdgcn_readlane((int)key, (int)j) < key ? 1u : 0u;
+            wave_sync();
+            if ((uint32_t)lane < m)
+                w.keys[rank] = key;
+            wave_sync();
+        }
+        else {
         // ---- bitonic sort of keys[0..P), P = power of two >= m, padded with the maximum ----
         uint32_t P = 2;
         while (P < m)
@@ -854,8 +869,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void deflate_codes_wave_kernel
                 wave_sync();
             }
         }
+        }
         if (stop_after == 1u)
-            return;             // phase 1: + bitonic sort
+            return;             // phase 1: + the sort
         // ---- two-queue Huffman merge; both queues live in registers ----
         if (m <= 63u) {
             // The usual case (a tile has a few dozen live symbols): one leaf and one internal node per lane, so
