@@ -1182,6 +1182,40 @@ __device__ __forceinline__ uint32_t copy_batch(Shared &sh, Output &o, const uint
                          : [a] "v"(a), [b] "v"(b), [at] "v"(at), [bt] "v"(bt), [M0] "s"(M[0]), [M1] "s"(M[1]), [M2] "s"(M[2]), [M3] "s"(M[3]), [M4] "s"(M[4]), [M5] "s"(M[5]), [M6] "s"(M[6]), [M7] "s"(M[7]), [M8] "s"(M[8]), [M9] "s"(M[9]), [M10] "s"(M[10]), [M11] "s"(M[11]), [M12] "s"(M[12]), [M13] "s"(M[13]), [M14] "s"(M[14]), [M15] "s"(M[15]), [T0] "s"(T[0]), [T1] "s"(T[1]), [T2] "s"(T[2])
                          : "memory");
         }
+        // F: matches whose source has left the ring (it lies in the tile's slot in HBM, flushed: copy_match()) and that
+        // are at most 64 bytes long, eight at a time: eight byte loads per lane in flight, one wait, eight LDS writes.
+        // One by one in stage C each was a memory round trip of its own behind a wait for all stores -- a noisy tile has
+        // 5 700 of them with the 8 KiB ring, a third of what was left of the copier's time (decoder_cycle_counters.txt).
+        // Their sources are final, they write only their own place: any time before the stages that may read them.
+        const bool far_short = is_match && l > 0u && l <= 64u && !near;
+        {
+            unsigned long long todo = __ballot(far_short);
+            if (todo != 0ull)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the flushes this wave has issued are in the slot
+            while (todo != 0ull) {
+                uint32_t f_dst[8], f_l[8];
+                uint8_t v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    f_l[k] = 0;
+                    f_dst[k] = 0;
+                    v[k] = 0;
+                    if (todo != 0ull) {
+                        const int i = __builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        f_dst[k] = (uint32_t)__builtin_amdgcn_readlane((int)dst, i);
+                        f_l[k] = (uint32_t)__builtin_amdgcn_readlane((int)l, i);
+                        const uint32_t from = f_dst[k] - (uint32_t)__builtin_amdgcn_readlane((int)dist, i);
+                        if ((uint32_t)lane < f_l[k])
+                            v[k] = o.out[from + (uint32_t)lane];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if ((uint32_t)lane < f_l[k])
+                        sh.window[(f_dst[k] + (uint32_t)lane) & kWindowMask] = v[k];
+            }
+        }
         // B2: long matches that read nothing of this sub-batch
         for (unsigned long long todo = __ballot(early_long); todo != 0ull; todo &= todo - 1ull) {
             const int i = __builtin_ctzll(todo);
@@ -1189,7 +1223,7 @@ __device__ __forceinline__ uint32_t copy_batch(Shared &sh, Output &o, const uint
                       (uint32_t)__builtin_amdgcn_readlane((int)l, i), lane);
         }
         // C: the other matches, in order
-        unsigned long long rest = __ballot(is_match && l > 0u && !early && !early_long);
+        unsigned long long rest = __ballot(is_match && l > 0u && !early && !early_long && !far_short);
         if (diag == 3u)
             rest = 0ull;                // (timing: without the matches carried out one by one)
         const uint32_t pos0 = o.pos;
