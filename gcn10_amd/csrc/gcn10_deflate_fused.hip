@@ -462,7 +462,7 @@ struct SharedFA2 {
         struct {
             uint32_t lit_hist[288];
             uint32_t dist_hist[2];
-            uint32_t n_c[256], w_c[256];
+            uint32_t n_c[2][256], w_c[2][256];  // two copies, by lane parity: half the lanes per LDS atomic on one class
             union {
                 uint32_t H[kGroup][256];                    // after the tokens are out
                 struct {
@@ -558,8 +558,8 @@ __global__ __launch_bounds__(kFA2Threads, 8) void fused_stats_seg_kernel(const F
     if (t < 2)
         sh.a.dist_hist[t] = 0;
     if (t < 256) {
-        sh.a.n_c[t] = 0;
-        sh.a.w_c[t] = 0;
+        sh.a.n_c[0][t] = sh.a.n_c[1][t] = 0;
+        sh.a.w_c[0][t] = sh.a.w_c[1][t] = 0;
     }
     if (t < GCN10_N_RASTERS) {
         sh.a.s1[t] = 0;
@@ -603,8 +603,8 @@ __global__ __launch_bounds__(kFA2Threads, 8) void fused_stats_seg_kernel(const F
             const uint32_t n = (uint32_t)(x1 - x0);
             const uint32_t c = rowp[seg * kSegPx + x0];
             // sum of (65536 - i) over i = i0 + x0 .. i0 + x1 - 1
-            atomicAdd(&sh.a.n_c[c], n);
-            atomicAdd(&sh.a.w_c[c], n * ((uint32_t)kTileBytes - i0) - ((n * (uint32_t)(x0 + x1 - 1)) >> 1));
+            atomicAdd(&sh.a.n_c[lane & 1][c], n);
+            atomicAdd(&sh.a.w_c[lane & 1][c], n * ((uint32_t)kTileBytes - i0) - ((n * (uint32_t)(x0 + x1 - 1)) >> 1));
         }
     }
 
@@ -801,13 +801,13 @@ __global__ __launch_bounds__(kFA2Threads, 8) void fused_stats_seg_kernel(const F
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const uint32_t c = (uint32_t)lane + 64u * (uint32_t)q;
-                const uint32_t n = sh.a.n_c[c];
+                const uint32_t n = sh.a.n_c[0][c] + sh.a.n_c[1][c];
                 if (n) {
                     const uint32_t v = val[c];
                     uint32_t h = (c * 0x9E3779B1u + v * 0x85EBCA6Bu + 0x27D4EB2Fu) * 0x165667B1u;
                     h ^= h >> 15;
                     a1 += n * v;
-                    a2 += (sh.a.w_c[c] % 65521u) * v;       // (<= 256 x 65520 x 255 < 2^32 over the tile)
+                    a2 += ((sh.a.w_c[0][c] % 65521u + sh.a.w_c[1][c] % 65521u) % 65521u) * v;       // (<= 256 x 65520 x 255 < 2^32 over the tile)
                     a3 += h;
                 }
             }
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(kFA2Threads, 8) void fused_stats_seg_kernel(const F
     // (b) rasters that cannot differ on this tile (see the row form): the hash proposes, a comparison class by
     // class confirms
     {
-        const bool present = cls && sh.a.n_c[t] != 0;
+        const bool present = cls && (sh.a.n_c[0][t] | sh.a.n_c[1][t]) != 0;
         __syncthreads();
         if ((uint32_t)t < job.n_sel) {
             uint32_t cand = 0xffu;
