@@ -24,6 +24,7 @@
 // DRAM traffic against ~20 VALU ops and 2 ds_read_b128 per pixel.
 
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 #include <hip/hip_ext.h>
 
 #include <cstdarg>
@@ -1158,6 +1159,20 @@ int gcn10_gpu_event_sync(gcn10_gpu_ctx *ctx, gcn10_event_t ev)
         return rc;
     if (!ev)
         return fail(GCN10_E_INVAL, "gcn10_gpu_event_sync: null event");
+    if (ctx->event_sync_sleep_us > 0) {
+        // a waiter that sleeps between queries: hipEventSynchronize spins in user mode for the whole wait, which is
+        // what a timing loop wants and what a thread of a CPU-quota-bound host pipeline does not (the threads that
+        // wait for a strip's bytes burnt 18 % of the program's CPU time: profiles/r03/host_cpu_by_thread_and_job.txt)
+        for (;;) {
+            const hipError_t e = hipEventQuery(reinterpret_cast<hipEvent_t>(ev));
+            if (e == hipSuccess)
+                break;
+            if (e != hipErrorNotReady)
+                HIP_TRY(e);
+            usleep((useconds_t)ctx->event_sync_sleep_us);
+        }
+        return GCN10_OK;
+    }
     HIP_TRY(hipEventSynchronize(reinterpret_cast<hipEvent_t>(ev)));
     return GCN10_OK;
 }
@@ -1560,6 +1575,7 @@ int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value)
         ctx->fused_stats_stop = fresh.fused_stats_stop;
         ctx->codes_stop = fresh.codes_stop;
         ctx->inflate_diag = fresh.inflate_diag;
+        ctx->event_sync_sleep_us = fresh.event_sync_sleep_us;
         ctx->single = fresh.single;
     }
     else if (!strcmp(name, "grid_blocks_per_cu") && value >= 1 && value <= 64)
@@ -1588,6 +1604,8 @@ int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value)
         ctx->fused_parse = value;
     else if (!strcmp(name, "fused_diag") && value >= 0 && value < 64)
         ctx->fused_diag = value;
+    else if (!strcmp(name, "event_sync_sleep_us") && value >= 0 && value <= 100000)
+        ctx->event_sync_sleep_us = value;
     else if (!strcmp(name, "inflate_diag") && value >= 0 && value < 8)
         ctx->inflate_diag = value;
     else if (!strcmp(name, "prefetch") && (value == -1 || value == 0 || value == 1))

@@ -77,6 +77,7 @@ struct gcn10_gpu_ctx {
     int fused_stats_stop = 0;       // timing experiments only: pass F-A leaves after phase (value - 1)
     int fused_diag = 0;             // timing experiments only (streams become invalid): 2 = pass F-C
                                     // without its token trips (set-up cost alone)
+    int event_sync_sleep_us = 0;    // gcn10_gpu_event_sync: 0 = hipEventSynchronize (spins); n > 0 = query, sleep n us, query ...
     int inflate_diag = 0;           // timing experiments only (output invalid): 1 = copier idle, 2 = empty batches
     bool fused_ready = false;
     bool codes_ready = false;       // LDS attribute of the per-thread code construction set

@@ -80,6 +80,7 @@ static void load_once(void)
     BIND(deflate_arena_bound); BIND(deflate_strip); BIND(pci_bus_id);
     BIND(deflate_fused_strip); BIND(deflate_fused_available); BIND(inflate_tiles);
 #undef BIND
+    *(void **)(&g_api.set_option) = dlsym(h, "gcn10_gpu_set_option");    /* tuning only: may be absent (tests' stand-in) */
     if (g_api.abi_version() != GCN10_GPU_ABI_VERSION) {
         snprintf(g_err, sizeof g_err, "%s has ABI version %d, expected %d", g_path,
                  g_api.abi_version(), GCN10_GPU_ABI_VERSION);

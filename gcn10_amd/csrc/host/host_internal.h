@@ -21,6 +21,7 @@ gcn10_pool *gcn10_pool_create(int n_threads);
 void gcn10_pool_submit(gcn10_pool *p, gcn10_job_fn fn, void *arg);
 void gcn10_pool_destroy(gcn10_pool *p);     /* drains the queue first */
 double gcn10_pool_cpu_seconds(gcn10_pool *p);   /* CPU time its (live) threads have used so far */
+double gcn10_pool_cpu_of(gcn10_pool *p, gcn10_job_fn fn, long *n_jobs);     /* ... in jobs of one kind */
 double gcn10_thread_cpu_seconds(void);          /* ... the calling thread */
 
 /* Like gcn10_tiff_read_window / gcn10_raster_read, with the tiles or strips of the
@@ -101,6 +102,7 @@ struct gcn10_gpu_api {
     size_t (*deflate_arena_bound)(int, int, int);
     int (*deflate_strip)(gcn10_gpu_ctx *, const uint8_t *const *, int, int, int, uint8_t *, size_t,
                          uint32_t *, unsigned long long *, gcn10_stream_t);
+    int (*set_option)(gcn10_gpu_ctx *, const char *, int);     /* optional (tuning): NULL when the library has none */
 };
 const struct gcn10_gpu_api *gcn10_gpu_api_get(char *err, size_t errcap);
 

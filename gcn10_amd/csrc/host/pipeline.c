@@ -877,6 +877,10 @@ static int worker_setup(struct worker *w)
 
         w->n_cus = cus > 0 ? cus : 256;
     }
+    /* waits for GPU events sleep between queries: the pool threads that wait for a strip's bytes, and this thread when
+     * it waits for a strip's table, would otherwise spin in user mode for the whole wait (GCN10_EVENT_SLEEP_US=0: spin) */
+    if (r->event_sleep_us > 0 && g->set_option)
+        (void)g->set_option(w->ctx, "event_sync_sleep_us", r->event_sleep_us);
     GPU_TRY(w, g->set_tables(w->ctx, &r->tables[0][0][0], 9));
     w->fused = r->fused && g->deflate_fused_available(w->ctx) == 1;
     if (r->fused && !w->fused)
@@ -1104,6 +1108,7 @@ int gcn10_run(const gcn10_run_options *opt)
         r->nbuf = n < 2 ? 2 : (n > MAX_NBUF ? MAX_NBUF : n);
     }
     r->drain_lag = 2;
+    r->event_sleep_us = getenv("GCN10_EVENT_SLEEP_US") ? atoi(getenv("GCN10_EVENT_SLEEP_US")) : 50;
     if (getenv("GCN10_DRAIN_LAG"))
         r->drain_lag = atoi(getenv("GCN10_DRAIN_LAG"));
     if (r->drain_lag < 1)
@@ -1385,6 +1390,19 @@ int gcn10_run(const gcn10_run_options *opt)
                     snprintf(msg, sizeof msg, "timing: host cpu seconds by thread: encoder workers %.3f, input threads %.3f, "
                              "i/o pool %.3f, others (HIP runtime, main) %.3f", enc, inp, io, cpu - enc - inp - io);
                     gcn10_log_message(log0, "INFO", msg, false);
+                    {
+                        long n_put = 0, n_gate = 0, n_fin = 0, n_row = 0;
+                        const double c_put = gcn10_pool_cpu_of(r->pool, put_tiles_job, &n_put);
+                        const double c_gate = gcn10_pool_cpu_of(r->pool, strip_gate_job, &n_gate);
+                        const double c_fin = gcn10_pool_cpu_of(r->pool, finish_tiff_job, &n_fin);
+                        const double c_row = gcn10_pool_cpu_of(r->pool, tile_row_job, &n_row);
+
+                        snprintf(msg, sizeof msg, "timing: i/o pool cpu seconds by job: appending a raster's strip %.3f (%ld), "
+                                 "waiting for a strip's bytes %.3f (%ld), finishing files %.3f (%ld), host deflate %.3f (%ld), "
+                                 "reading and decoding inputs %.3f", c_put, n_put, c_gate, n_gate, c_fin, n_fin, c_row, n_row,
+                                 io - c_put - c_gate - c_fin - c_row);
+                        gcn10_log_message(log0, "INFO", msg, false);
+                    }
                 }
             }
         }

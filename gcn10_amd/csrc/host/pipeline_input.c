@@ -498,6 +498,8 @@ int gcn10_input_setup(struct worker *w)
      * context is not shared between threads (include/gcn10_gpu.h); device memory and events are valid
      * in both, they belong to the device */
     GPU_IN(w, g->init(w->device, &w->in_ctx));
+    if (w->run->event_sleep_us > 0 && g->set_option)
+        (void)g->set_option(w->in_ctx, "event_sync_sleep_us", w->run->event_sleep_us);
     GPU_IN(w, g->stream_create(w->in_ctx, &w->s_in));
     for (int k = 0; k < N_RING; k++)
         GPU_IN(w, g->event_create(w->in_ctx, &w->ev_ring[k]));

@@ -135,6 +135,7 @@ struct run {
     atomic_int fatal;                       /* a worker hit an MPI_Abort-class error */
     int strip_rows;                         /* "strip_rows" of the config, rounded up to whole tile rows */
     int nbuf;                               /* strip buffer sets per worker (GCN10_STRIP_BUFFERS, 2..8) */
+    int event_sleep_us;                     /* GPU events are waited for with query + sleep (0: the runtime's spinning wait) */
     int drain_lag;                          /* the strip handed to the sink while strip s is submitted: s - drain_lag */
     int deflate_level;
     bool null_sink;                         /* GCN10_SINK=null: no compression, no files */

@@ -25,7 +25,10 @@ struct gcn10_pool {
     pthread_cond_t cv;
     struct job *head, *tail;
     bool stop;
+    struct { gcn10_job_fn fn; double cpu; long n; } by_fn[16];   /* CPU time by kind of job (timing lines) */
 };
+
+double gcn10_thread_cpu_seconds(void);
 
 static void *pool_main(void *arg)
 {
@@ -46,8 +49,26 @@ static void *pool_main(void *arg)
         if (!p->head)
             p->tail = NULL;
         pthread_mutex_unlock(&p->mu);
-        j->fn(j->arg);
-        free(j);
+        {
+            const double c0 = gcn10_thread_cpu_seconds();
+            const gcn10_job_fn fn = j->fn;
+
+            j->fn(j->arg);
+            free(j);
+            {
+                const double used = gcn10_thread_cpu_seconds() - c0;
+
+                pthread_mutex_lock(&p->mu);
+                for (int k = 0; k < 16; k++)
+                    if (p->by_fn[k].fn == fn || !p->by_fn[k].fn) {
+                        p->by_fn[k].fn = fn;
+                        p->by_fn[k].cpu += used;
+                        p->by_fn[k].n++;
+                        break;
+                    }
+                pthread_mutex_unlock(&p->mu);
+            }
+        }
     }
 }
 
@@ -56,6 +77,25 @@ double gcn10_thread_cpu_seconds(void)
     struct timespec ts;
 
     return clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) == 0 ? (double)ts.tv_sec + ts.tv_nsec * 1e-9 : 0.0;
+}
+
+double gcn10_pool_cpu_of(gcn10_pool *p, gcn10_job_fn fn, long *n_jobs)
+{
+    double cpu = 0.0;
+
+    if (n_jobs)
+        *n_jobs = 0;
+    if (!p)
+        return 0.0;
+    pthread_mutex_lock(&p->mu);
+    for (int k = 0; k < 16; k++)
+        if (p->by_fn[k].fn == fn) {
+            cpu = p->by_fn[k].cpu;
+            if (n_jobs)
+                *n_jobs = p->by_fn[k].n;
+        }
+    pthread_mutex_unlock(&p->mu);
+    return cpu;
 }
 
 double gcn10_pool_cpu_seconds(gcn10_pool *p)
