@@ -23,6 +23,7 @@ void gcn10_pool_destroy(gcn10_pool *p);     /* drains the queue first */
 double gcn10_pool_cpu_seconds(gcn10_pool *p);   /* CPU time its (live) threads have used so far */
 double gcn10_pool_cpu_of(gcn10_pool *p, gcn10_job_fn fn, long *n_jobs);     /* ... in jobs of one kind */
 double gcn10_thread_cpu_seconds(void);          /* ... the calling thread */
+void gcn10_tiff_cache_stats(uint64_t *hits, uint64_t *misses, size_t *bytes);     /* decoded-chunk cache of tiff.c */
 
 /* Like gcn10_tiff_read_window / gcn10_raster_read, with the tiles or strips of the
  * window decoded concurrently on `pool` (NULL = on the calling thread). */

@@ -1402,6 +1402,15 @@ int gcn10_run(const gcn10_run_options *opt)
                                  "reading and decoding inputs %.3f", c_put, n_put, c_gate, n_gate, c_fin, n_fin, c_row, n_row,
                                  io - c_put - c_gate - c_fin - c_row);
                         gcn10_log_message(log0, "INFO", msg, false);
+                        {
+                            uint64_t hits = 0, misses = 0;
+                            size_t held = 0;
+
+                            gcn10_tiff_cache_stats(&hits, &misses, &held);
+                            snprintf(msg, sizeof msg, "timing: decoded-chunk cache (soil strips): %llu hits, %llu misses, %.1f MB held",
+                                     (unsigned long long)hits, (unsigned long long)misses, (double)held / 1e6);
+                            gcn10_log_message(log0, "INFO", msg, false);
+                        }
                     }
                 }
             }

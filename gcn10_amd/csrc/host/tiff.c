@@ -47,6 +47,7 @@ struct gcn10_tiff {
     uint64_t *offsets, *counts;
     uint64_t n_chunks;
     uint64_t file_size;
+    uint64_t id_dev, id_ino;    /* which file (the chunk cache is shared by every open handle of it) */
     double gt[6];
     gcn10_georef georef;
 };
@@ -201,6 +202,8 @@ struct gcn10_tiff *gcn10_tiff_open_reader(const char *path, char *err, size_t er
         if (fstat(t->fd, &st) != 0 || st.st_size < 8)
             goto badfile;
         t->file_size = (uint64_t)st.st_size;
+        t->id_dev = (uint64_t)st.st_dev;
+        t->id_ino = (uint64_t)st.st_ino;
     }
     if (hdr[0] == 'I' && hdr[1] == 'I')
         t->swap = false;
@@ -610,6 +613,146 @@ static int decode_chunk(struct gcn10_tiff *t, uint64_t idx, unsigned char *buf, 
     return 0;
 }
 
+/* Decoded chunks that windows use a small part of.  The soil raster is a global file of full-width strips: a
+ * block's window needs 1/120 of each strip it touches, and the ~120 blocks of a latitude band need the SAME strips,
+ * one block after the other (the queue hands out ids in shapefile order).  Decoding a strip once per block was the
+ * largest item of the host's CPU time without the file sink (profiles/r03/host_cpu_by_thread_and_job.txt).
+ * One cache per process, shared by every handle of a file (workers open their own), least recently used out first;
+ * GCN10_CHUNK_CACHE_MB (default 512, 0 = none).  Entries in use (being copied from) are not evicted. */
+struct cache_entry {
+    uint64_t dev, ino, idx;
+    unsigned char *data;
+    size_t bytes;
+    uint64_t stamp;
+    int refs;
+};
+
+static struct {
+    pthread_mutex_t mu;
+    struct cache_entry **e;     /* heap objects: a pinned entry is referred to by pointer while others come and go */
+    int n, cap_entries;
+    size_t bytes, cap_bytes;
+    uint64_t clock, hits, misses;
+    bool ready;
+} g_cache = { .mu = PTHREAD_MUTEX_INITIALIZER };
+
+static void cache_init_locked(void)
+{
+    const char *mb = getenv("GCN10_CHUNK_CACHE_MB");
+
+    g_cache.cap_bytes = (size_t)(mb ? strtoull(mb, NULL, 10) : 512) << 20;
+    g_cache.ready = true;
+}
+
+/* the chunk's decoded bytes (pinned until cache_release), or NULL */
+static struct cache_entry *cache_get(const struct gcn10_tiff *t, uint64_t idx, size_t bytes)
+{
+    struct cache_entry *hit = NULL;
+
+    pthread_mutex_lock(&g_cache.mu);
+    if (!g_cache.ready)
+        cache_init_locked();
+    for (int i = 0; i < g_cache.n; i++) {
+        struct cache_entry *c = g_cache.e[i];
+
+        if (c->idx == idx && c->ino == t->id_ino && c->dev == t->id_dev && c->bytes == bytes) {
+            c->refs++;
+            c->stamp = ++g_cache.clock;
+            hit = c;
+            break;
+        }
+    }
+    if (hit)
+        g_cache.hits++;
+    else
+        g_cache.misses++;
+    pthread_mutex_unlock(&g_cache.mu);
+    return hit;
+}
+
+static void cache_release(struct cache_entry *c)
+{
+    pthread_mutex_lock(&g_cache.mu);
+    c->refs--;
+    pthread_mutex_unlock(&g_cache.mu);
+}
+
+/* hands `data` (malloc'ed, `bytes` long) to the cache; returns the entry to read from (pinned), or NULL when the cache
+ * does not take it (the caller keeps and frees `data`) */
+static struct cache_entry *cache_put(const struct gcn10_tiff *t, uint64_t idx, unsigned char *data, size_t bytes)
+{
+    struct cache_entry *res = NULL;
+
+    pthread_mutex_lock(&g_cache.mu);
+    if (bytes <= g_cache.cap_bytes / 4) {
+        for (int i = 0; i < g_cache.n; i++) {       /* decoded by another thread meanwhile: use theirs */
+            struct cache_entry *c = g_cache.e[i];
+
+            if (c->idx == idx && c->ino == t->id_ino && c->dev == t->id_dev && c->bytes == bytes) {
+                c->refs++;
+                pthread_mutex_unlock(&g_cache.mu);
+                free(data);
+                return c;
+            }
+        }
+        while (g_cache.bytes + bytes > g_cache.cap_bytes) {      /* least recently used, not in use, out */
+            int victim = -1;
+
+            for (int i = 0; i < g_cache.n; i++)
+                if (g_cache.e[i]->refs == 0 && (victim < 0 || g_cache.e[i]->stamp < g_cache.e[victim]->stamp))
+                    victim = i;
+            if (victim < 0)
+                break;
+            g_cache.bytes -= g_cache.e[victim]->bytes;
+            free(g_cache.e[victim]->data);
+            free(g_cache.e[victim]);
+            g_cache.e[victim] = g_cache.e[--g_cache.n];
+        }
+        if (g_cache.bytes + bytes <= g_cache.cap_bytes) {
+            if (g_cache.n == g_cache.cap_entries) {
+                int cap = g_cache.cap_entries ? g_cache.cap_entries * 2 : 4096;
+                struct cache_entry **g = realloc(g_cache.e, (size_t)cap * sizeof *g);
+
+                if (g) {
+                    g_cache.e = g;
+                    g_cache.cap_entries = cap;
+                }
+            }
+            if (g_cache.n < g_cache.cap_entries && (res = malloc(sizeof *res)) != NULL) {
+                *res = (struct cache_entry){ t->id_dev, t->id_ino, idx, data, bytes, ++g_cache.clock, 1 };
+                g_cache.e[g_cache.n++] = res;
+                g_cache.bytes += bytes;
+            }
+        }
+    }
+    pthread_mutex_unlock(&g_cache.mu);
+    return res;
+}
+
+static bool cache_enabled(void)
+{
+    bool on;
+
+    pthread_mutex_lock(&g_cache.mu);
+    if (!g_cache.ready)
+        cache_init_locked();
+    on = g_cache.cap_bytes > 0;
+    pthread_mutex_unlock(&g_cache.mu);
+    return on;
+}
+
+void gcn10_tiff_cache_stats(uint64_t *hits, uint64_t *misses, size_t *bytes)
+{
+    pthread_mutex_lock(&g_cache.mu);
+    if (hits)
+        *hits = g_cache.hits;
+    if (misses)
+        *misses = g_cache.misses;
+    if (bytes)
+        *bytes = g_cache.bytes;
+    pthread_mutex_unlock(&g_cache.mu);
+}
+
 /* one chunk (tile or strip) of a window read: decode and copy the overlap */
 struct chunk_job {
     struct gcn10_tiff *t;
@@ -650,20 +793,52 @@ static int read_chunk(const struct chunk_job *j)
     }
     if (xs >= xe || ys >= ye)
         return 0;
-    if (decode_chunk(t, (uint64_t)j->cy * t->across + j->cx, raw, rawcap, &scratch, &scratch_cap,
-                     rows_in_chunk, ((size_t)(ye - 1 - y_lo) * t->cw + (xe - x_lo)) * t->spp) != 0)
-        return -1;
-    for (uint32_t y = ys; y < ye; y++) {
-        const unsigned char *s = raw + ((size_t)(y - y_lo) * t->cw + (xs - x_lo)) * t->spp;
-        uint8_t *d = j->dst + (size_t)(y - (uint32_t)j->yoff) * j->dst_stride + (xs - (uint32_t)j->xoff);
+    {
+        const uint64_t idx = (uint64_t)j->cy * t->across + j->cx;
+        const size_t chunk_bytes = (size_t)t->cw * rows_in_chunk * t->spp;
+        const unsigned char *from = raw;
+        struct cache_entry *held = NULL;
 
-        if (t->spp == 1) {
-            memcpy(d, s, xe - xs);
+        /* a compressed chunk the window uses at most a quarter of: through the cache, decoded in full */
+        if (t->compression != 1 && (size_t)(xe - xs) * (ye - ys) * t->spp * 4 <= chunk_bytes &&
+            cache_enabled()) {
+            held = cache_get(t, idx, chunk_bytes);
+            if (!held) {
+                unsigned char *whole = malloc(chunk_bytes);
+
+                if (whole && decode_chunk(t, idx, whole, chunk_bytes, &scratch, &scratch_cap, rows_in_chunk, chunk_bytes) == 0) {
+                    held = cache_put(t, idx, whole, chunk_bytes);
+                    if (!held) {            /* not taken: copy from our own buffer below, then free it */
+                        memcpy(raw, whole, chunk_bytes <= rawcap ? chunk_bytes : rawcap);
+                        free(whole);
+                    }
+                }
+                else {
+                    free(whole);
+                    return -1;
+                }
+            }
+            if (held)
+                from = held->data;
         }
-        else {
-            for (uint32_t x = 0; x < xe - xs; x++)
-                d[x] = s[(size_t)x * t->spp];
+        else if (decode_chunk(t, idx, raw, rawcap, &scratch, &scratch_cap, rows_in_chunk,
+                              ((size_t)(ye - 1 - y_lo) * t->cw + (xe - x_lo)) * t->spp) != 0) {
+            return -1;
         }
+        for (uint32_t y = ys; y < ye; y++) {
+            const unsigned char *s = from + ((size_t)(y - y_lo) * t->cw + (xs - x_lo)) * t->spp;
+            uint8_t *d = j->dst + (size_t)(y - (uint32_t)j->yoff) * j->dst_stride + (xs - (uint32_t)j->xoff);
+
+            if (t->spp == 1) {
+                memcpy(d, s, xe - xs);
+            }
+            else {
+                for (uint32_t x = 0; x < xe - xs; x++)
+                    d[x] = s[(size_t)x * t->spp];
+            }
+        }
+        if (held)
+            cache_release(held);
     }
     return 0;
 }

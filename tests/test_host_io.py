@@ -149,6 +149,36 @@ def test_tiff_reader_variants(tmp_path, kw):
             r.read(90, 0, 20, 5)
 
 
+@pytest.mark.parametrize("kw", [dict(compression=5, rows_per_strip=8), dict(compression=8, rows_per_strip=3, predictor=2),
+                                dict(compression=8, tile=(256, 64))],
+                         ids=["lzw strips", "deflate strips + predictor", "deflate tiles"])
+def test_windows_that_use_a_small_part_of_their_chunks_go_through_the_chunk_cache(tmp_path, kw):
+    """Round 3: a window that uses at most a quarter of a compressed chunk (the soil raster: full-width strips, a
+    block needs 1/120 of each) reads it through a per-process cache of decoded chunks, shared by every handle of the
+    file.  Narrow windows side by side, from two handles, a second pass (all hits), windows that straddle chunk
+    borders and the ragged last strip: every read equals the source, and the cache reports the hits."""
+    import ctypes as C
+    img = _img(77, 61, 1500)
+    p = str(tmp_path / "wide.tif")
+    tiffutil.write_tiff(p, img, gt=GT, **kw)
+    L = host.lib()
+    L.gcn10_tiff_cache_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)]
+    L.gcn10_tiff_cache_stats.restype = None
+    h0, m0, b0 = C.c_uint64(), C.c_uint64(), C.c_size_t()
+    L.gcn10_tiff_cache_stats(C.byref(h0), C.byref(m0), C.byref(b0))
+    with host.Raster(p) as a, host.Raster(p) as b:
+        for rep in range(2):
+            for k, x in enumerate(range(0, 1500 - 40, 97)):
+                r = a if k % 2 else b
+                assert np.array_equal(r.read(x, 5, 40, 50), img[5:55, x:x + 40])
+        assert np.array_equal(a.read(1460, 58, 40, 3), img[58:61, 1460:1500])      # the ragged last strip
+        assert np.array_equal(a.read(0, 0, 1500, 61), img)                           # a window that uses all of them: not cached
+    h1, m1, b1 = C.c_uint64(), C.c_uint64(), C.c_size_t()
+    L.gcn10_tiff_cache_stats(C.byref(h1), C.byref(m1), C.byref(b1))
+    assert m1.value > m0.value and h1.value - h0.value > 4 * (m1.value - m0.value)
+    assert b1.value > 0
+
+
 def test_tiff_reader_pillow_written_files(tmp_path):
     img = _img(5, 300, 257)
     for comp in ("raw", "tiff_lzw", "tiff_adobe_deflate", "packbits"):

@@ -13,7 +13,7 @@ for io in 0; do
     if [ $sink = null ]; then export GCN10_SINK=null; else unset GCN10_SINK; fi
     $R/bin/gcn10 -c config.txt -o --gpus 1 > /dev/null 2>&1
     echo "io_threads=$io sink=$sink"
-    grep -h "timing: steady\|host cpu\|pool cpu" logs/rank_0.log | sed 's/^[^]]*\] //' | cut -c1-420
+    grep -h "timing: steady\|host cpu\|pool cpu\|chunk cache" logs/rank_0.log | sed 's/^[^]]*\] //' | cut -c1-420
   done
 done
 which strace perf ltrace 2>/dev/null
