@@ -799,6 +799,27 @@ static int read_chunk(const struct chunk_job *j)
         const unsigned char *from = raw;
         struct cache_entry *held = NULL;
 
+        /* an uncompressed chunk the window uses at most a quarter of (full-width strips): the wanted part of every
+         * row straight from the file -- reading the chunk from its start to the last wanted pixel copied ~120 times
+         * the bytes a block of a global raster needs */
+        if (t->compression == 1 && t->predictor != 2 && t->spp == 1 &&
+            (size_t)(xe - xs) * (ye - ys) * 4 <= chunk_bytes) {
+            const uint64_t off = t->offsets[idx], cnt = t->counts[idx];
+
+            if (cnt == 0) {
+                for (uint32_t y = ys; y < ye; y++)
+                    memset(j->dst + (size_t)(y - (uint32_t)j->yoff) * j->dst_stride + (xs - (uint32_t)j->xoff), 0, xe - xs);
+                return 0;
+            }
+            if (off > t->file_size || cnt > t->file_size - off ||
+                cnt < ((size_t)(ye - 1 - y_lo) * t->cw + (xe - x_lo)))
+                return -1;
+            for (uint32_t y = ys; y < ye; y++)
+                if (pread_all(t->fd, j->dst + (size_t)(y - (uint32_t)j->yoff) * j->dst_stride + (xs - (uint32_t)j->xoff),
+                              xe - xs, off + (uint64_t)(y - y_lo) * t->cw + (xs - x_lo)) != 0)
+                    return -1;
+            return 0;
+        }
         /* a compressed chunk the window uses at most a quarter of: through the cache, decoded in full */
         if (t->compression != 1 && (size_t)(xe - xs) * (ye - ys) * t->spp * 4 <= chunk_bytes &&
             cache_enabled()) {

@@ -150,8 +150,8 @@ def test_tiff_reader_variants(tmp_path, kw):
 
 
 @pytest.mark.parametrize("kw", [dict(compression=5, rows_per_strip=8), dict(compression=8, rows_per_strip=3, predictor=2),
-                                dict(compression=8, tile=(256, 64))],
-                         ids=["lzw strips", "deflate strips + predictor", "deflate tiles"])
+                                dict(compression=8, tile=(256, 64)), dict(compression=1, rows_per_strip=8)],
+                         ids=["lzw strips", "deflate strips + predictor", "deflate tiles", "raw strips (row reads, no cache)"])
 def test_windows_that_use_a_small_part_of_their_chunks_go_through_the_chunk_cache(tmp_path, kw):
     """Round 3: a window that uses at most a quarter of a compressed chunk (the soil raster: full-width strips, a
     block needs 1/120 of each) reads it through a per-process cache of decoded chunks, shared by every handle of the
@@ -175,8 +175,9 @@ def test_windows_that_use_a_small_part_of_their_chunks_go_through_the_chunk_cach
         assert np.array_equal(a.read(0, 0, 1500, 61), img)                           # a window that uses all of them: not cached
     h1, m1, b1 = C.c_uint64(), C.c_uint64(), C.c_size_t()
     L.gcn10_tiff_cache_stats(C.byref(h1), C.byref(m1), C.byref(b1))
-    assert m1.value > m0.value and h1.value - h0.value > 4 * (m1.value - m0.value)
-    assert b1.value > 0
+    if kw["compression"] != 1:
+        assert m1.value > m0.value and h1.value - h0.value > 4 * (m1.value - m0.value)
+        assert b1.value > 0
 
 
 def test_tiff_reader_pillow_written_files(tmp_path):
