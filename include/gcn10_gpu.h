@@ -15,7 +15,10 @@
  * behaviour.
  *
  * Threading: a context belongs to one GPU and is used by one host thread at a
- * time (the reference runs one thread per rank, src/main.c:171-176).
+ * time (the reference runs one thread per rank, src/main.c:171-176).  The one
+ * exception: gcn10_gpu_event_sync() only reads the context and may be called by
+ * other threads while its owner works (the host pipeline's I/O threads wait for
+ * a strip's copy-back that way).
  *
  * There is no CPU fallback behind this ABI: every call needs a live gfx950
  * device, and gcn10_gpu_init() fails loudly without one.
