@@ -262,7 +262,13 @@ int gcn10_gpu_inflate_tiles(gcn10_gpu_ctx *ctx, const uint8_t *comp_dev,
  * and strips of 16-byte aligned rows read, the compact soil words; default 1), "deflate_wave_codes" (0|1: code
  * construction of the tile encoder by one thread or one wave per tile), "fused_diag" (timing
  * experiments on the fused encoder; nonzero values produce invalid streams), "defaults" (value
- * ignored: every knob back to its built-in default). */
+ * ignored: every knob back to its built-in default).
+ * Round 3: "arena_segment_align" (16..4096, a power of two; default 4096: every raster's extent of a strip starts at a
+ * multiple of it in the arena), "fused_parse" / "fused_emit" (0 = the round-2 forms of the fused encoder's first and
+ * last pass, kept as cross-checks; 1 = default; the streams are the same bytes), "fused_stats_stop", "codes_stop",
+ * "inflate_diag" (timing experiments, like "fused_diag"), "event_sync_sleep_us" (0 = default: gcn10_gpu_event_sync
+ * is hipEventSynchronize, which spins; n > 0: it queries the event and sleeps n microseconds in between -- what a
+ * host pipeline's waiting threads want). */
 int gcn10_gpu_set_option(gcn10_gpu_ctx *ctx, const char *name, int value);
 
 /* Measurement: the next gcn10_gpu_cn_strip launch records `start` / `stop` as part of
