@@ -423,19 +423,30 @@ __device__ __forceinline__ uint32_t slow_symbol(const Reader &r, const uint16_t 
 }
 
 struct Output {
-    uint8_t *out;           // this tile's slot in HBM, 16-byte aligned
+    uint8_t *out;           // this tile's slot in HBM, 16-byte aligned -- or, for a tile decoded in place, the first
+                            // byte of its window in the destination raster
     uint32_t limit;         // bytes wanted
     uint32_t pos;           // bytes produced
     uint32_t flushed;       // bytes already in HBM (multiple of kFlush)
+    // A tile decoded IN PLACE (round 3): the whole chunk is wanted, it is a power of two wide and its rows start on
+    // 16-byte boundaries of the destination, so decoded byte p goes straight to row p / width, column p % width of the
+    // raster -- no slot, no pass of untile_kernel over it (94 % of a block's tiles: all but its last row and column).
+    uint32_t wshift;        // log2(chunk width); 0 = the linear slot
+    uint32_t wmask;
+    unsigned long long stride;
 };
+
+__device__ __forceinline__ uint8_t *out_at(const Output &o, uint32_t p)
+{
+    return o.wshift ? o.out + (size_t)(p >> o.wshift) * o.stride + (p & o.wmask) : o.out + p;
+}
 
 __device__ __forceinline__ void flush_half(Shared &sh, Output &o, int lane)
 {
     const u32x4 *src = reinterpret_cast<const u32x4 *>(sh.window + (o.flushed & kWindowMask));
-    u32x4 *dst = reinterpret_cast<u32x4 *>(o.out + o.flushed);
 #pragma unroll 4
     for (int i = lane; i < kFlush / 16; i += 64)
-        dst[i] = src[i];
+        *reinterpret_cast<u32x4 *>(out_at(o, o.flushed + 16u * (uint32_t)i)) = src[i];      // (16 bytes never leave a row: widths are multiples of 16)
     o.flushed += kFlush;
 }
 
@@ -455,7 +466,7 @@ __device__ __forceinline__ void copy_match(Shared &sh, Output &o, uint32_t len, 
 #pragma unroll
         for (int i = 0; i < 5; i++) {
             const uint32_t k = (uint32_t)lane + 64u * (uint32_t)i;
-            v[i] = k < len ? o.out[from + k] : (uint8_t)0;
+            v[i] = k < len ? *out_at(o, from + k) : (uint8_t)0;
         }
 #pragma unroll
         for (int i = 0; i < 5; i++) {
@@ -1207,7 +1218,7 @@ __device__ __forceinline__ uint32_t copy_batch(Shared &sh, Output &o, const uint
                         f_l[k] = (uint32_t)__builtin_amdgcn_readlane((int)l, i);
                         const uint32_t from = f_dst[k] - (uint32_t)__builtin_amdgcn_readlane((int)dist, i);
                         if ((uint32_t)lane < f_l[k])
-                            v[k] = o.out[from + (uint32_t)lane];
+                            v[k] = *out_at(o, from + (uint32_t)lane);
                     }
                 }
 #pragma unroll
@@ -1247,6 +1258,15 @@ __device__ __forceinline__ uint32_t copy_batch(Shared &sh, Output &o, const uint
     return 0;
 }
 
+// A tile inflate_kernel decodes straight into the destination raster (and untile_kernel leaves alone): see Output.
+__device__ __forceinline__ bool tile_in_place(const TileIn &t, uint32_t slot_bytes, const uint8_t *dst, unsigned long long dst_stride)
+{
+    const uint32_t w = t.chunk_w;
+    return !(t.flags & (GCN10_TILE_RAW | GCN10_TILE_PREDICTOR2)) && w >= 16u && (w & (w - 1u)) == 0u && t.src_x == 0u &&
+           t.src_y == 0u && t.copy_w == w && t.copy_h > 0u && (unsigned long long)t.copy_h * w == t.out_len &&
+           t.out_len <= slot_bytes && ((reinterpret_cast<uintptr_t>(dst) | t.dst_off | dst_stride) & 15u) == 0u;
+}
+
 // One workgroup of two wavefronts per stream: wave 0 decodes bits into tokens, wave 1 carries
 // the tokens out; they swap halves of a small token ring at a barrier every kBatch tokens.
 // diag (gcn10_gpu_set_option "inflate_diag", timing experiments only, output invalid; 3 = the copier skips the
@@ -1254,7 +1274,7 @@ __device__ __forceinline__ uint32_t copy_batch(Shared &sh, Output &o, const uint
 // carries nothing out, 2 = the decoder hands over empty batches after decoding them
 __global__ __launch_bounds__(128) void inflate_kernel(const uint8_t *comp, const TileIn *tiles, uint32_t n_tiles,
                                                       uint8_t *scratch, uint32_t slot_bytes, uint32_t *status,
-                                                      uint32_t diag)
+                                                      uint32_t diag, uint8_t *dst, unsigned long long dst_stride)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Shared &sh = *reinterpret_cast<Shared *>(smem);
@@ -1289,6 +1309,14 @@ __global__ __launch_bounds__(128) void inflate_kernel(const uint8_t *comp, const
     d.last = false;
     Output o;
     o.out = scratch + (size_t)tile * slot_bytes;
+    o.wshift = o.wmask = 0;
+    o.stride = 0;
+    if (tile_in_place(tin, slot_bytes, dst, dst_stride)) {
+        o.out = dst + tin.dst_off;
+        o.wshift = 31u - (uint32_t)__builtin_clz(tin.chunk_w);
+        o.wmask = tin.chunk_w - 1u;
+        o.stride = dst_stride;
+    }
     o.limit = d.limit;
     o.pos = 0;
     o.flushed = 0;
@@ -1346,9 +1374,9 @@ __global__ __launch_bounds__(128) void inflate_kernel(const uint8_t *comp, const
     {
         const uint32_t end = o.pos < o.limit ? o.pos : o.limit;
         for (uint32_t i = o.flushed + (uint32_t)lane; i < end; i += 64)
-            o.out[i] = sh.window[i & kWindowMask];
+            *out_at(o, i) = sh.window[i & kWindowMask];
         for (uint32_t i = end + (uint32_t)lane; i < tin.out_len && i < slot_bytes; i += 64)
-            o.out[i] = 0;
+            *out_at(o, i) = 0;
     }
     if (lane == 0)
         status[tile] = err;
@@ -1368,6 +1396,8 @@ __global__ __launch_bounds__(256) void untile_kernel(const TileIn *tiles, const 
     if (!window_ok(tin.out_len, tin.chunk_w, tin.src_x, tin.src_y, tin.copy_w, tin.copy_h, raw ? 0xffffffffu : slot_bytes) ||
         (raw && tin.in_len < tin.out_len))
         return;                                 // inflate_kernel has set the status
+    if (tile_in_place(tin, slot_bytes, dst, dst_stride))
+        return;                                 // inflate_kernel has written its rows where they belong
     const uint8_t *chunk = raw ? comp + tin.in_off : scratch + (size_t)blockIdx.x * slot_bytes;
     uint8_t *out = dst + tin.dst_off;
     const int lane = (int)(threadIdx.x & 63u);
@@ -1467,7 +1497,7 @@ int gcn10_gpu_inflate_tiles(gcn10_gpu_ctx *ctx, const uint8_t *comp_dev, const g
     uint8_t *scratch = reinterpret_cast<uint8_t *>(ctx->inflate_ws);
     hipLaunchKernelGGL(inflate_kernel, dim3((uint32_t)n_tiles), dim3(128), sizeof(Shared), s, comp_dev,
                        reinterpret_cast<const TileIn *>(tiles_dev), (uint32_t)n_tiles, scratch, slot, status_dev,
-                       (uint32_t)ctx->inflate_diag);
+                       (uint32_t)ctx->inflate_diag, dst_dev, (unsigned long long)dst_stride);
     hipLaunchKernelGGL(untile_kernel, dim3((uint32_t)n_tiles, 16), dim3(256), 0, s,
                        reinterpret_cast<const TileIn *>(tiles_dev), scratch, slot, comp_dev, dst_dev,
                        (unsigned long long)dst_stride);

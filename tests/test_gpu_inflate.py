@@ -303,10 +303,15 @@ def test_matches_of_every_length_from_far_and_near_sources(engine, seed):
         w.match(length, min(dist, have))
         if k % 5 == 0:
             w.literal(int(rng.integers(0, 256)))
+    while len(w.raw) % 1024:
+        w.literal(int(rng.integers(0, 256)))
     stream, raw = w.finish()
     assert zlib.decompress(stream) == raw
-    out, status = _one(engine, stream, len(raw))
+    out, status = _one(engine, stream, len(raw))                # one row: through the tile's slot and untile_kernel
     assert status == 0
+    assert out.tobytes() == raw
+    out, status = _one(engine, stream, len(raw), w=1024)        # rows of 1024: decoded in place (matches that read
+    assert status == 0                                          # flushed bytes read them from the raster's rows)
     assert out.tobytes() == raw
 
 

@@ -99,7 +99,8 @@ def run(seed=1, seconds=None, streams_budget=None, batch=256, verbose=True):
     with gpu.Engine(0) as e:
         while time.time() < t_end and n_streams < budget:
             streams, raws, rows = [], [], []
-            W = 4096
+            # (rows of a power of two: tiles decoded in place; 4080: through their slots and untile_kernel)
+            W = 4096 if rng.random() < 0.5 else 4080
             for k in range(a.batch):
                 n = int(rng.integers(1, 300000)) if rng.random() < 0.9 else int(rng.integers(300000, 1 << 20))
                 raw = gen(rng, n)
